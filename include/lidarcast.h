@@ -1,0 +1,177 @@
+/*
+ * lidarcast.h -- C ABI of liblidarcast, the MI355X (gfx950) LiDAR ray-cast scan engine.
+ *
+ * The reference has no FFI on this path: its engine boundary is the Python ABC
+ * RaycastEngineBase (raycast_engine/raycast_engine.py:16-61) whose concrete classes call
+ * open3d.t.geometry.RaycastingScene (raycast_engine/raycast_engine_cpu.py:46-51,
+ * raycast_engine/raycast_engine_gpu_simple.py:41-46).  The entry points below are what a
+ * ctypes binding of that boundary needs ("Suggested C exports"); each
+ * one names the reference call it stands in for.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 (LRC_OK) or a negative LRC_ERR_* code;
+ *     lrc_last_error() returns a thread-local, NUL-terminated description of the last failure.
+ *   - no exception, abort() or longjmp crosses this boundary.
+ *   - the caller allocates inputs and outputs; the library owns only the opaque handles.
+ *   - "host" entry points take host pointers, copy, run the HIP kernels and copy back
+ *     (synchronous on return).  "_dev" entry points take DEVICE pointers and a hipStream_t
+ *     (passed as void*; NULL = the null stream) and only enqueue work.
+ *   - handles are not thread-safe; use one context per thread.
+ *
+ * Hit definition (oracle/lrc_oracle.c restates it on the CPU)
+ *   Two-sided closest hit, t in (0, +inf), t parametric along the GIVEN direction (the direction
+ *   is not normalised, as in Open3D), miss = +inf / prim 0xFFFFFFFF, ties broken by the smaller
+ *   triangle row index.  float32 throughout with a fixed fused-multiply-add expression tree.
+ */
+#ifndef LIDARCAST_H
+#define LIDARCAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRC_OK                 0
+#define LRC_ERR_INVALID_ARG  (-1)   /* NULL pointer, bad size, triangle index out of range      */
+#define LRC_ERR_NO_DEVICE    (-2)   /* no HIP device / device ordinal out of range              */
+#define LRC_ERR_HIP          (-3)   /* a HIP runtime call failed; text in lrc_last_error()      */
+#define LRC_ERR_OOM          (-4)   /* host or device allocation failed                         */
+#define LRC_ERR_INTERNAL     (-5)
+
+#define LRC_INVALID_PRIM  0xFFFFFFFFu
+
+typedef struct lrc_ctx   lrc_ctx;     /* one HIP device + scratch buffers                       */
+typedef struct lrc_scene lrc_scene;   /* one triangle mesh + its BVH, resident in HBM           */
+
+/* Per-ray hit attributes, structure-of-arrays.  Every pointer may be NULL (attribute skipped).
+ * Arrays hold one entry per ray (cast) or P*N entries, pose-major (scan).
+ * Replaces the result dict of RaycastingScene.cast_rays (raycast_engine_cpu.py:51-53:
+ * t_hit, primitive_ids, primitive_normals) plus the numpy post-processing that follows it. */
+typedef struct lrc_hits {
+    float*    t;             /* (n)    parametric range; +inf = miss or removed by the range filter */
+    uint32_t* prim;          /* (n)    triangle row index in the caller's array; LRC_INVALID_PRIM   */
+    float*    normal3;       /* (n,3)  unit geometric normal normalize((v1-v0)x(v2-v0)); 0 on miss   */
+    float*    point3;        /* (n,3)  o + (d/|d|)*t in float32, mul then add
+                                       (raycast_engine_cpu.py:57-62); 0 on miss                      */
+    uint16_t* sem;           /* (n)    semantic label of the hit triangle; 0 on miss                 */
+    uint16_t* ins;           /* (n)    instance label of the hit triangle; 0 on miss                 */
+    double*   incident_deg;  /* (n)    degrees(arccos(|((p-c)/|p-c|)_z|)) in float64
+                                       (raycast_engine_cpu.py:100-107); 0 on miss                    */
+} lrc_hits;
+
+typedef struct lrc_scene_info {
+    uint64_t num_vertices;
+    uint64_t num_triangles;
+    uint64_t num_nodes;        /* inner nodes of the binary BVH (64 B each)                      */
+    uint64_t num_leaves;
+    uint64_t num_slots;        /* triangle records in leaf order (48 B each), == num_triangles   */
+    uint32_t max_depth;        /* root = depth 0; bounded by LRC_MAX_BVH_DEPTH                   */
+    uint32_t max_leaf_size;
+    uint64_t device_bytes;     /* HBM held by this scene                                         */
+    double   build_ms;         /* host BVH build time                                            */
+    double   upload_ms;
+    float    bounds_lo[3];
+    float    bounds_hi[3];
+} lrc_scene_info;
+
+#define LRC_MAX_BVH_DEPTH 32
+
+/* Library version string, e.g. "lidarcast 0.1.0 (gfx950)". */
+const char* lrc_version(void);
+
+/* Thread-local text of the last error raised on this thread ("" if none). */
+const char* lrc_last_error(void);
+
+/* Number of visible HIP devices (0 when there is none); never fails. */
+int lrc_device_count(void);
+
+/* Bind a context to HIP device `device`.  Fails with LRC_ERR_NO_DEVICE on a box without a GPU so
+ * that RaycastEngineGPU() raises and the caller's try/except (s3dis_simulator.py:66-74) can act. */
+int lrc_ctx_create(int device, lrc_ctx** out_ctx);
+int lrc_ctx_destroy(lrc_ctx* ctx);
+int lrc_ctx_synchronize(lrc_ctx* ctx);
+
+/* Build the scene once per mesh: narrow-free copy of float32 vertices (V,3) and uint32 triangle
+ * rows (T,3), host SAH BVH build, upload.  tri_sem / tri_ins are optional per-triangle labels.
+ * Replaces RaycastingScene() + TriangleMesh.from_legacy + add_triangles, which the reference
+ * repeats on every call (raycast_engine_cpu.py:46-47, raycast_engine.py:20-24).
+ * T == 0 is allowed (every ray misses). */
+int lrc_scene_create(lrc_ctx* ctx,
+                     const float* verts3, uint64_t num_vertices,
+                     const uint32_t* tris3, uint64_t num_triangles,
+                     const uint16_t* tri_sem, const uint16_t* tri_ins,
+                     lrc_scene** out_scene);
+int lrc_scene_destroy(lrc_scene* scene);
+int lrc_scene_get_info(const lrc_scene* scene, lrc_scene_info* out_info);
+
+/* Copy the BVH back to host arrays (tests check its invariants).  Any pointer may be NULL.
+ *   nodes64 : num_nodes * 16 floats  (lo0 xyz, hi0 xyz, lo1 xyz, hi1 xyz, ref0, ref1, 0, 0; refs are
+ *             int32 bit patterns: >=0 inner node index, <0 leaf: ~ref = first_slot*8 + (count-1))
+ *   slot_prim: num_slots uint32 (triangle row index stored in each leaf slot) */
+int lrc_scene_export_bvh(const lrc_scene* scene, float* nodes16, uint32_t* slot_prim);
+
+/* ---- cast: explicit rays --------------------------------------------------------------------
+ * rays6 is (N,6) float32 rows [ox,oy,oz,dx,dy,dz] (raycast_engine_cpu.py:24-38).
+ * center3 (3 doubles, may be NULL) and max_range implement lidar_intersect_mesh's range filter
+ * (raycast_engine_cpu.py:95-97): a hit is kept iff |float64(point) - center| < max_range (strict);
+ * removed hits are reported exactly like misses.  With center3 == NULL nothing is filtered and
+ * incident_deg is measured from the ray origin.
+ * Replaces RaycastingScene.cast_rays + the numpy block raycast_engine_cpu.py:50-73. */
+int lrc_cast(lrc_scene* scene, const float* rays6, uint64_t num_rays,
+             const double* center3, double max_range, const lrc_hits* out);
+int lrc_cast_dev(lrc_scene* scene, const float* d_rays6, uint64_t num_rays,
+                 const double* center3 /* HOST pointer, 3 doubles or NULL */, double max_range,
+                 const lrc_hits* d_out, void* stream);
+
+/* ---- scan: pose-batched, rays generated in the kernel -------------------------------------------
+ * poses16: (P,16) float64 row-major 4x4 sensor poses (Waypoint.to_pose_matrix,
+ *          trajectory/trajectory_generator.py:30-44).
+ * dirs3  : (N,3) float64 sensor-frame unit directions, line-major/azimuth-minor
+ *          (IndoorLidar._gen_lidar_rays_with_vertical_degrees, lidar/indoor_lidar.py:108-126).
+ * Ray (p,i): origin = float32(pose[:3,3]); direction = float32(dirs3[i] @ R^T) evaluated in
+ * float64 left to right (lidar/indoor_lidar.py:127-131); then exactly lrc_cast with
+ * center = pose[:3,3] and max_range.  Output index = p*N + i.
+ * Replaces the per-waypoint loop body s3dis_simulator.py:254-264. */
+int lrc_scan_poses(lrc_scene* scene, const double* poses16, uint64_t num_poses,
+                   const double* dirs3, uint64_t rays_per_pose, double max_range,
+                   const lrc_hits* out);
+int lrc_scan_poses_dev(lrc_scene* scene, const double* d_poses16, uint64_t num_poses,
+                       const double* d_dirs3, uint64_t rays_per_pose, double max_range,
+                       const lrc_hits* d_out, void* stream);
+
+/* ---- compaction: fixed-stride records -> the reference's variable-length frames ----------------
+ * Stable compaction, in (segment, ray) order, of the entries whose t is finite.  `t` holds
+ * num_segments * seg_len entries.  counts[s] receives the number kept in segment s;
+ * the kept entries of all segments are packed back to back, which is the order of
+ * np.vstack over frames (containers/s3dis_sim_scene.py:326,362).  Optional gathers (NULL = skip):
+ * point3 -> out_point3 (K,3), sem/ins -> out_sem/out_ins (K), incident -> out_incident (K),
+ * out_index (K) = index of the kept entry inside its segment.
+ * Host variant returns the total K in *out_total. */
+typedef struct lrc_compact_io {
+    const float*    t;
+    const float*    point3;
+    const uint16_t* sem;
+    const uint16_t* ins;
+    const double*   incident_deg;
+    uint64_t*       counts;        /* (num_segments)                                  */
+    float*          out_point3;
+    uint16_t*       out_sem;
+    uint16_t*       out_ins;
+    double*         out_incident_deg;
+    uint32_t*       out_index;
+} lrc_compact_io;
+
+int lrc_compact(lrc_ctx* ctx, uint64_t num_segments, uint64_t seg_len,
+                const lrc_compact_io* io, uint64_t* out_total);
+int lrc_compact_dev(lrc_ctx* ctx, uint64_t num_segments, uint64_t seg_len,
+                    const lrc_compact_io* d_io, void* stream);
+
+/* Number of traversal-kernel launches and rays issued on this scene so far (bench bookkeeping). */
+int lrc_scene_get_counters(const lrc_scene* scene, uint64_t* launches, uint64_t* rays);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDARCAST_H */

@@ -1,0 +1,678 @@
+// lidarcast.hip -- HIP kernels and C ABI of liblidarcast (gfx950 / MI355X only).
+//
+// Implements include/lidarcast.h.  Replaces, behind the reference's engine boundary
+// (raycast_engine/raycast_engine.py:16-61), the Open3D/Embree work of
+// raycast_engine/raycast_engine_cpu.py:46-73 and the numpy post-processing of :95-107,
+// and, for pose batches, the per-waypoint loop body of s3dis_simulator.py:254-264.
+//
+// Kernels
+//   trace_kernel<GEN>   one lane per ray; while-while BVH2 traversal with the per-lane stack in LDS
+//                       ([depth][lane], conflict free), fused hit write-back (t, prim, normal, point,
+//                       labels, range filter, incident angle).  GEN = rays generated from
+//                       (pose, direction table) inside the kernel.
+//   compact_*           stable stream compaction of the fixed-stride records into frame order.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/lidarcast.h"
+#include "lrc_bvh.h"
+#include "lrc_device.h"
+
+using namespace lrcdev;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define LRC_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            (void)hipGetLastError();                                                       \
+            return fail(e__ == hipErrorOutOfMemory ? LRC_ERR_OOM : LRC_ERR_HIP,            \
+                        std::string(#call) + ": " + hipGetErrorString(e__));               \
+        }                                                                                  \
+    } while (0)
+
+constexpr int kBlock = 256;
+constexpr int kStack = LRC_MAX_BVH_DEPTH;
+
+}  // namespace
+
+struct lrc_ctx {
+    int device = 0;
+    // compaction scratch (grown on demand, reused)
+    uint64_t* d_block_off = nullptr;
+    uint64_t block_off_cap = 0;
+};
+
+struct lrc_scene {
+    lrc_ctx* ctx = nullptr;
+    float4* d_nodes = nullptr;
+    float4* d_tris = nullptr;
+    uint32_t* d_slot_prim = nullptr;
+    uint32_t* d_slot_label = nullptr;
+    lrc_scene_info info{};
+    uint64_t launches = 0, rays = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// device code
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct TraceParams {
+    const float4* nodes;
+    const float4* tris;
+    const uint32_t* slot_prim;
+    const uint32_t* slot_label;
+    uint32_t num_nodes;
+    // inputs
+    const float* rays6;        // explicit rays (GEN = false)
+    const double* poses16;     // GEN = true
+    const double* dirs3;       // GEN = true
+    uint64_t rays_per_pose;
+    uint64_t total;
+    int has_center;
+    double cx, cy, cz;
+    double max_range;
+    lrc_hits out;
+};
+
+// workgroup -> tile remap: consecutive tiles land on the same XCD (blocks b, b+8, ... share an L2),
+// so each XCD's 4 MiB L2 keeps the part of the scene its run of poses/scanlines looks at.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nwg) {
+    uint32_t q = nwg >> 3, r = nwg & 7u, x = b & 7u;
+    uint32_t base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (b >> 3);
+}
+
+__device__ __forceinline__ V3 ld3(const float4 a) { return V3{a.x, a.y, a.z}; }
+
+template <bool GEN>
+__global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams p) {
+    __shared__ int s_stack[kStack * kBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t gid = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * kBlock + tid;
+    if (gid >= p.total) return;
+
+    // ---- the ray ----
+    V3 o, d;
+    double cx, cy, cz;
+    if (GEN) {
+        const uint64_t pose = gid / p.rays_per_pose;
+        const uint64_t i = gid - pose * p.rays_per_pose;
+        const double* M = p.poses16 + pose * 16;
+        const double* dv = p.dirs3 + i * 3;
+        const double a = dv[0], b = dv[1], c = dv[2];
+        // rays_d = np.dot(directions, R.T) in float64, then .astype(float32)  (indoor_lidar.py:127-131)
+        d.x = (float)((a * M[0] + b * M[1]) + c * M[2]);
+        d.y = (float)((a * M[4] + b * M[5]) + c * M[6]);
+        d.z = (float)((a * M[8] + b * M[9]) + c * M[10]);
+        cx = M[3]; cy = M[7]; cz = M[11];
+        o.x = (float)cx; o.y = (float)cy; o.z = (float)cz;
+    } else {
+        const float* r = p.rays6 + gid * 6;
+        o.x = r[0]; o.y = r[1]; o.z = r[2];
+        d.x = r[3]; d.y = r[4]; d.z = r[5];
+        if (p.has_center) { cx = p.cx; cy = p.cy; cz = p.cz; }
+        else { cx = (double)o.x; cy = (double)o.y; cz = (double)o.z; }
+    }
+
+    // ---- closest hit ----
+    const RaySlab sl = make_slab(o, d);
+    float tbest = __builtin_inff();
+    uint32_t best_slot = 0xFFFFFFFFu;
+    uint32_t best_prim = 0xFFFFFFFFu;   // loaded lazily, only to break exact ties
+
+    if (p.num_nodes) {
+        int sp = 0;
+        int ref = 0;   // root
+        while (true) {
+            // descend inner nodes
+            while (ref >= 0) {
+                const float4* n = p.nodes + (size_t)ref * 4;
+                const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+                float n0, f0, n1, f1;
+                slab_interval(sl, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, n0, f0);
+                slab_interval(sl, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, n1, f1);
+                const bool h0 = (n0 <= f0) & (n0 <= tbest);
+                const bool h1 = (n1 <= f1) & (n1 <= tbest);
+                const int r0 = __float_as_int(q3.x), r1 = __float_as_int(q3.y);
+                if (h0 & h1) {
+                    const bool first0 = n0 <= n1;
+                    s_stack[sp * kBlock + tid] = first0 ? r1 : r0;
+                    ++sp;
+                    ref = first0 ? r0 : r1;
+                } else if (h0) {
+                    ref = r0;
+                } else if (h1) {
+                    ref = r1;
+                } else {
+                    if (sp == 0) goto done;
+                    --sp;
+                    ref = s_stack[sp * kBlock + tid];
+                }
+            }
+            // leaf
+            {
+                const uint32_t enc = (uint32_t)(~ref);
+                const uint32_t first = enc >> 3, cnt = enc & 7u;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const uint32_t slot = first + k;
+                    const float4* tr = p.tris + (size_t)slot * 3;
+                    const float4 a = tr[0], b = tr[1], c = tr[2];
+                    const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
+                    float t;
+                    if (tri_hit(o, d, sl, v0, v1, v2, ng, t)) {
+                        if (t < tbest) {
+                            tbest = t; best_slot = slot; best_prim = 0xFFFFFFFFu;
+                        } else if (t == tbest) {
+                            if (best_prim == 0xFFFFFFFFu) best_prim = p.slot_prim[best_slot];
+                            const uint32_t pr = p.slot_prim[slot];
+                            if (pr < best_prim) { best_slot = slot; best_prim = pr; }
+                        }
+                    }
+                }
+            }
+            if (sp == 0) break;
+            --sp;
+            ref = s_stack[sp * kBlock + tid];
+        }
+    }
+done:
+
+    // ---- fused write-back ----
+    bool keep = best_slot != 0xFFFFFFFFu;
+    float t_out = __builtin_inff();
+    uint32_t prim = LRC_INVALID_PRIM;
+    float nx = 0.f, ny = 0.f, nz = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+    uint32_t label = 0;
+    double inc = 0.0;
+    if (keep) {
+        // p = o + (d/|d|)*t : numpy float32, one rounding per operation (raycast_engine_cpu.py:57-62)
+        const float nrm = __builtin_sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z);
+        const float hx = d.x / nrm, hy = d.y / nrm, hz = d.z / nrm;
+        px = o.x + hx * tbest; py = o.y + hy * tbest; pz = o.z + hz * tbest;
+        // range filter + incident angle in float64 (raycast_engine_cpu.py:95-107)
+        const double ex = (double)px - cx, ey = (double)py - cy, ez = (double)pz - cz;
+        const double dist = __builtin_sqrt((ex * ex + ey * ey) + ez * ez);
+        if (p.has_center || GEN) keep = dist < p.max_range;
+        if (keep) {
+            t_out = tbest;
+            prim = p.slot_prim[best_slot];
+            label = p.slot_label[best_slot];
+            if (p.out.normal3) {
+                const float4 c = p.tris[(size_t)best_slot * 3 + 2];
+                const float len = __builtin_sqrtf(fma_(c.w, c.w, fma_(c.z, c.z, c.y * c.y)));
+                nx = c.y / len; ny = c.z / len; nz = c.w / len;
+            }
+            if (p.out.incident_deg) inc = acos(__builtin_fabs(ez / dist)) * kRadToDeg;
+        } else {
+            px = py = pz = 0.f;
+        }
+    }
+    if (p.out.t) p.out.t[gid] = t_out;
+    if (p.out.prim) p.out.prim[gid] = prim;
+    if (p.out.normal3) { float* q = p.out.normal3 + gid * 3; q[0] = nx; q[1] = ny; q[2] = nz; }
+    if (p.out.point3) { float* q = p.out.point3 + gid * 3; q[0] = px; q[1] = py; q[2] = pz; }
+    if (p.out.sem) p.out.sem[gid] = (uint16_t)(label & 0xFFFFu);
+    if (p.out.ins) p.out.ins[gid] = (uint16_t)(label >> 16);
+    if (p.out.incident_deg) p.out.incident_deg[gid] = inc;
+}
+
+// ---- compaction -------------------------------------------------------------------------------
+// block b <-> (segment b / bps, chunk b % bps); each block covers kBlock consecutive entries.
+
+__global__ __launch_bounds__(kBlock) void compact_count_kernel(const float* t, uint64_t seg_len,
+                                                               uint64_t bps, uint64_t* block_cnt) {
+    __shared__ uint32_t s_w[kBlock / 64];
+    const uint64_t b = blockIdx.x;
+    const uint64_t seg = b / bps, chunk = b - seg * bps;
+    const uint64_t i = chunk * kBlock + threadIdx.x;
+    bool keep = false;
+    if (i < seg_len) keep = t[seg * seg_len + i] < __builtin_inff();
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t c = 0;
+        for (int w = 0; w < kBlock / 64; ++w) c += s_w[w];
+        block_cnt[b] = c;
+    }
+}
+
+// single workgroup: exclusive scan of nblocks counts in place, total at [nblocks], then segment counts
+__global__ __launch_bounds__(1024) void compact_scan_kernel(uint64_t* block_off, uint64_t nblocks,
+                                                            uint64_t bps, uint64_t nseg,
+                                                            uint64_t* seg_counts) {
+    __shared__ uint64_t s_part[1024];
+    __shared__ uint64_t s_carry;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < nblocks; base += 1024) {
+        const uint64_t i = base + tid;
+        const uint64_t v = i < nblocks ? block_off[i] : 0;
+        s_part[tid] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+            uint64_t add = tid >= off ? s_part[tid - off] : 0;
+            __syncthreads();
+            s_part[tid] += add;
+            __syncthreads();
+        }
+        const uint64_t carry = s_carry;
+        if (i < nblocks) block_off[i] = carry + s_part[tid] - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + s_part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) block_off[nblocks] = s_carry;
+    __threadfence_block();
+    __syncthreads();
+    if (seg_counts) {
+        for (uint64_t s = tid; s < nseg; s += 1024)
+            seg_counts[s] = block_off[(s + 1) * bps] - block_off[s * bps];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const lrc_compact_io io,
+                                                                 uint64_t seg_len, uint64_t bps,
+                                                                 const uint64_t* block_off) {
+    __shared__ uint32_t s_w[kBlock / 64];
+    const uint64_t b = blockIdx.x;
+    const uint64_t seg = b / bps, chunk = b - seg * bps;
+    const uint64_t i = chunk * kBlock + threadIdx.x;
+    const uint64_t src = seg * seg_len + i;
+    bool keep = false;
+    if (i < seg_len) keep = io.t[src] < __builtin_inff();
+    const unsigned long long m = __ballot(keep);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (lane == 0) s_w[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (!keep) return;
+    uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (uint32_t k = 0; k < w; ++k) before += s_w[k];
+    const uint64_t dst = block_off[b] + before;
+    if (io.out_point3) {
+        const float* s = io.point3 + src * 3;
+        float* q = io.out_point3 + dst * 3;
+        q[0] = s[0]; q[1] = s[1]; q[2] = s[2];
+    }
+    if (io.out_sem) io.out_sem[dst] = io.sem[src];
+    if (io.out_ins) io.out_ins[dst] = io.ins[src];
+    if (io.out_incident_deg) io.out_incident_deg[dst] = io.incident_deg[src];
+    if (io.out_index) io.out_index[dst] = (uint32_t)i;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* lrc_version(void) { return "lidarcast 0.1.0 (gfx950)"; }
+
+const char* lrc_last_error(void) { return g_err.c_str(); }
+
+int lrc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int lrc_ctx_create(int device, lrc_ctx** out_ctx) {
+    if (!out_ctx) return fail(LRC_ERR_INVALID_ARG, "lrc_ctx_create: out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = lrc_device_count();
+    if (n <= 0) return fail(LRC_ERR_NO_DEVICE, "lrc_ctx_create: no HIP device is visible");
+    if (device < 0 || device >= n)
+        return fail(LRC_ERR_NO_DEVICE, "lrc_ctx_create: device ordinal out of range");
+    LRC_HIP(hipSetDevice(device));
+    lrc_ctx* c = new (std::nothrow) lrc_ctx();
+    if (!c) return fail(LRC_ERR_OOM, "lrc_ctx_create: out of host memory");
+    c->device = device;
+    *out_ctx = c;
+    return LRC_OK;
+}
+
+int lrc_ctx_destroy(lrc_ctx* ctx) {
+    if (!ctx) return LRC_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_block_off) (void)hipFree(ctx->d_block_off);
+    delete ctx;
+    return LRC_OK;
+}
+
+int lrc_ctx_synchronize(lrc_ctx* ctx) {
+    if (!ctx) return fail(LRC_ERR_INVALID_ARG, "lrc_ctx_synchronize: ctx is NULL");
+    LRC_HIP(hipSetDevice(ctx->device));
+    LRC_HIP(hipDeviceSynchronize());
+    return LRC_OK;
+}
+
+int lrc_scene_destroy(lrc_scene* s) {
+    if (!s) return LRC_OK;
+    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    if (s->d_nodes) (void)hipFree(s->d_nodes);
+    if (s->d_tris) (void)hipFree(s->d_tris);
+    if (s->d_slot_prim) (void)hipFree(s->d_slot_prim);
+    if (s->d_slot_label) (void)hipFree(s->d_slot_label);
+    delete s;
+    return LRC_OK;
+}
+
+int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32_t* tris3, uint64_t T,
+                     const uint16_t* tri_sem, const uint16_t* tri_ins, lrc_scene** out_scene) {
+    if (!out_scene) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: out_scene is NULL");
+    *out_scene = nullptr;
+    if (!ctx) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: ctx is NULL");
+    if ((V && !verts3) || (T && !tris3))
+        return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: NULL vertex or triangle array");
+    if (T >= (1ull << 28) || V >= (1ull << 32))
+        return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: mesh too large (T < 2^28, V < 2^32)");
+    for (uint64_t i = 0; i < 3 * T; ++i)
+        if (tris3[i] >= V)
+            return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: triangle index out of range");
+    for (uint64_t i = 0; i < 3 * V; ++i)
+        if (!(std::fabs(verts3[i]) <= 1.0e6f))
+            return fail(LRC_ERR_INVALID_ARG,
+                        "lrc_scene_create: vertex coordinate is not finite or exceeds 1e6");
+    LRC_HIP(hipSetDevice(ctx->device));
+
+    lrc_scene* s = new (std::nothrow) lrc_scene();
+    if (!s) return fail(LRC_ERR_OOM, "lrc_scene_create: out of host memory");
+    s->ctx = ctx;
+
+    lrc::HostBVH h;
+    lrc::BuildOptions opt;
+    if (const char* e = std::getenv("LRC_MAX_LEAF")) opt.max_leaf = std::atoi(e);
+    auto t0 = std::chrono::steady_clock::now();
+    try {
+        lrc::build_bvh(verts3, V, tris3, T, tri_sem, tri_ins, opt, &h);
+    } catch (const std::bad_alloc&) {
+        delete s;
+        return fail(LRC_ERR_OOM, "lrc_scene_create: out of host memory during the BVH build");
+    } catch (...) {
+        delete s;
+        return fail(LRC_ERR_INTERNAL, "lrc_scene_create: BVH build failed");
+    }
+    auto t1 = std::chrono::steady_clock::now();
+
+    lrc_scene_info& in = s->info;
+    in.num_vertices = V;
+    in.num_triangles = T;
+    in.num_nodes = h.num_nodes;
+    in.num_leaves = h.num_leaves;
+    in.num_slots = h.num_slots;
+    in.max_depth = h.max_depth;
+    in.max_leaf_size = h.max_leaf_size;
+    for (int k = 0; k < 3; ++k) { in.bounds_lo[k] = h.bounds_lo[k]; in.bounds_hi[k] = h.bounds_hi[k]; }
+    in.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+
+    auto upload = [&](void** dptr, const void* src, size_t bytes) -> int {
+        if (!bytes) return LRC_OK;
+        LRC_HIP(hipMalloc(dptr, bytes));
+        LRC_HIP(hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice));
+        in.device_bytes += bytes;
+        return LRC_OK;
+    };
+    int rc;
+    if ((rc = upload((void**)&s->d_nodes, h.nodes.data(), h.nodes.size() * 4)) ||
+        (rc = upload((void**)&s->d_tris, h.tri_rec.data(), h.tri_rec.size() * 4)) ||
+        (rc = upload((void**)&s->d_slot_prim, h.slot_prim.data(), h.slot_prim.size() * 4)) ||
+        (rc = upload((void**)&s->d_slot_label, h.slot_label.data(), h.slot_label.size() * 4))) {
+        std::string keep = g_err;
+        lrc_scene_destroy(s);
+        g_err = keep;
+        return rc;
+    }
+    auto t2 = std::chrono::steady_clock::now();
+    in.upload_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    *out_scene = s;
+    return LRC_OK;
+}
+
+int lrc_scene_get_info(const lrc_scene* scene, lrc_scene_info* out_info) {
+    if (!scene || !out_info) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_get_info: NULL argument");
+    *out_info = scene->info;
+    return LRC_OK;
+}
+
+int lrc_scene_get_counters(const lrc_scene* scene, uint64_t* launches, uint64_t* rays) {
+    if (!scene) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_get_counters: scene is NULL");
+    if (launches) *launches = scene->launches;
+    if (rays) *rays = scene->rays;
+    return LRC_OK;
+}
+
+int lrc_scene_export_bvh(const lrc_scene* s, float* nodes16, uint32_t* slot_prim) {
+    if (!s) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_export_bvh: scene is NULL");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    if (nodes16 && s->info.num_nodes)
+        LRC_HIP(hipMemcpy(nodes16, s->d_nodes, s->info.num_nodes * 64, hipMemcpyDeviceToHost));
+    if (slot_prim && s->info.num_slots)
+        LRC_HIP(hipMemcpy(slot_prim, s->d_slot_prim, s->info.num_slots * 4, hipMemcpyDeviceToHost));
+    return LRC_OK;
+}
+
+static int launch_trace(lrc_scene* s, TraceParams& p, bool gen, hipStream_t st) {
+    p.nodes = s->d_nodes;
+    p.tris = s->d_tris;
+    p.slot_prim = s->d_slot_prim;
+    p.slot_label = s->d_slot_label;
+    p.num_nodes = (uint32_t)s->info.num_nodes;
+    if (p.total == 0) return LRC_OK;
+    const uint64_t nblk = (p.total + kBlock - 1) / kBlock;
+    if (nblk > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "too many rays for one launch");
+    if (gen)
+        hipLaunchKernelGGL(trace_kernel<true>, dim3((uint32_t)nblk), dim3(kBlock), 0, st, p);
+    else
+        hipLaunchKernelGGL(trace_kernel<false>, dim3((uint32_t)nblk), dim3(kBlock), 0, st, p);
+    LRC_HIP(hipGetLastError());
+    s->launches += 1;
+    s->rays += p.total;
+    return LRC_OK;
+}
+
+int lrc_cast_dev(lrc_scene* s, const float* d_rays6, uint64_t n, const double* center3,
+                 double max_range, const lrc_hits* d_out, void* stream) {
+    if (!s || !d_out) return fail(LRC_ERR_INVALID_ARG, "lrc_cast_dev: NULL scene or output");
+    if (n && !d_rays6) return fail(LRC_ERR_INVALID_ARG, "lrc_cast_dev: rays6 is NULL");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    TraceParams p{};
+    p.rays6 = d_rays6;
+    p.total = n;
+    p.rays_per_pose = n ? n : 1;
+    p.has_center = center3 != nullptr;
+    if (center3) { p.cx = center3[0]; p.cy = center3[1]; p.cz = center3[2]; }
+    p.max_range = max_range;
+    p.out = *d_out;
+    return launch_trace(s, p, false, (hipStream_t)stream);
+}
+
+int lrc_scan_poses_dev(lrc_scene* s, const double* d_poses16, uint64_t P, const double* d_dirs3,
+                       uint64_t N, double max_range, const lrc_hits* d_out, void* stream) {
+    if (!s || !d_out) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_poses_dev: NULL scene or output");
+    if (P && N && (!d_poses16 || !d_dirs3))
+        return fail(LRC_ERR_INVALID_ARG, "lrc_scan_poses_dev: poses16 or dirs3 is NULL");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    TraceParams p{};
+    p.poses16 = d_poses16;
+    p.dirs3 = d_dirs3;
+    p.rays_per_pose = N ? N : 1;
+    p.total = P * N;
+    p.has_center = 1;
+    p.max_range = max_range;
+    p.out = *d_out;
+    return launch_trace(s, p, true, (hipStream_t)stream);
+}
+
+// ---- host-pointer convenience wrappers ---------------------------------------------------------
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+struct HitsStage {
+    DevBuf t, prim, normal3, point3, sem, ins, inc;
+    lrc_hits d{};
+    int alloc(const lrc_hits& h, uint64_t n) {
+        if (!n) return LRC_OK;
+        if (h.t) { LRC_HIP(hipMalloc(&t.p, n * 4)); d.t = (float*)t.p; }
+        if (h.prim) { LRC_HIP(hipMalloc(&prim.p, n * 4)); d.prim = (uint32_t*)prim.p; }
+        if (h.normal3) { LRC_HIP(hipMalloc(&normal3.p, n * 12)); d.normal3 = (float*)normal3.p; }
+        if (h.point3) { LRC_HIP(hipMalloc(&point3.p, n * 12)); d.point3 = (float*)point3.p; }
+        if (h.sem) { LRC_HIP(hipMalloc(&sem.p, n * 2)); d.sem = (uint16_t*)sem.p; }
+        if (h.ins) { LRC_HIP(hipMalloc(&ins.p, n * 2)); d.ins = (uint16_t*)ins.p; }
+        if (h.incident_deg) { LRC_HIP(hipMalloc(&inc.p, n * 8)); d.incident_deg = (double*)inc.p; }
+        return LRC_OK;
+    }
+    int download(const lrc_hits& h, uint64_t n) {
+        if (!n) return LRC_OK;
+        if (h.t) LRC_HIP(hipMemcpy(h.t, d.t, n * 4, hipMemcpyDeviceToHost));
+        if (h.prim) LRC_HIP(hipMemcpy(h.prim, d.prim, n * 4, hipMemcpyDeviceToHost));
+        if (h.normal3) LRC_HIP(hipMemcpy(h.normal3, d.normal3, n * 12, hipMemcpyDeviceToHost));
+        if (h.point3) LRC_HIP(hipMemcpy(h.point3, d.point3, n * 12, hipMemcpyDeviceToHost));
+        if (h.sem) LRC_HIP(hipMemcpy(h.sem, d.sem, n * 2, hipMemcpyDeviceToHost));
+        if (h.ins) LRC_HIP(hipMemcpy(h.ins, d.ins, n * 2, hipMemcpyDeviceToHost));
+        if (h.incident_deg) LRC_HIP(hipMemcpy(h.incident_deg, d.incident_deg, n * 8, hipMemcpyDeviceToHost));
+        return LRC_OK;
+    }
+};
+}  // namespace
+
+int lrc_cast(lrc_scene* s, const float* rays6, uint64_t n, const double* center3, double max_range,
+             const lrc_hits* out) {
+    if (!s || !out) return fail(LRC_ERR_INVALID_ARG, "lrc_cast: NULL scene or output");
+    if (n && !rays6) return fail(LRC_ERR_INVALID_ARG, "lrc_cast: rays6 is NULL");
+    if (!n) return LRC_OK;
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    DevBuf rays;
+    LRC_HIP(hipMalloc(&rays.p, n * 24));
+    LRC_HIP(hipMemcpy(rays.p, rays6, n * 24, hipMemcpyHostToDevice));
+    HitsStage st;
+    int rc = st.alloc(*out, n);
+    if (rc) return rc;
+    rc = lrc_cast_dev(s, (const float*)rays.p, n, center3, max_range, &st.d, nullptr);
+    if (rc) return rc;
+    LRC_HIP(hipDeviceSynchronize());
+    return st.download(*out, n);
+}
+
+int lrc_scan_poses(lrc_scene* s, const double* poses16, uint64_t P, const double* dirs3, uint64_t N,
+                   double max_range, const lrc_hits* out) {
+    if (!s || !out) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_poses: NULL scene or output");
+    if (P && N && (!poses16 || !dirs3))
+        return fail(LRC_ERR_INVALID_ARG, "lrc_scan_poses: poses16 or dirs3 is NULL");
+    const uint64_t n = P * N;
+    if (!n) return LRC_OK;
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    DevBuf dp, dd;
+    LRC_HIP(hipMalloc(&dp.p, P * 128));
+    LRC_HIP(hipMalloc(&dd.p, N * 24));
+    LRC_HIP(hipMemcpy(dp.p, poses16, P * 128, hipMemcpyHostToDevice));
+    LRC_HIP(hipMemcpy(dd.p, dirs3, N * 24, hipMemcpyHostToDevice));
+    HitsStage st;
+    int rc = st.alloc(*out, n);
+    if (rc) return rc;
+    rc = lrc_scan_poses_dev(s, (const double*)dp.p, P, (const double*)dd.p, N, max_range, &st.d, nullptr);
+    if (rc) return rc;
+    LRC_HIP(hipDeviceSynchronize());
+    return st.download(*out, n);
+}
+
+int lrc_compact_dev(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_compact_io* io,
+                    void* stream) {
+    if (!ctx || !io) return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: NULL argument");
+    if (nseg == 0 || seg_len == 0) return LRC_OK;
+    if (!io->t) return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: t is NULL");
+    if ((io->out_point3 && !io->point3) || (io->out_sem && !io->sem) || (io->out_ins && !io->ins) ||
+        (io->out_incident_deg && !io->incident_deg))
+        return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: an output is requested without its input");
+    LRC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t bps = (seg_len + kBlock - 1) / kBlock;
+    const uint64_t nblocks = nseg * bps;
+    if (nblocks > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: too many entries");
+    if (ctx->block_off_cap < nblocks + 1) {
+        if (ctx->d_block_off) { (void)hipFree(ctx->d_block_off); ctx->d_block_off = nullptr; }
+        ctx->block_off_cap = 0;
+        LRC_HIP(hipMalloc((void**)&ctx->d_block_off, (nblocks + 1) * 8));
+        ctx->block_off_cap = nblocks + 1;
+    }
+    hipLaunchKernelGGL(compact_count_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, io->t,
+                       seg_len, bps, ctx->d_block_off);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, ctx->d_block_off, nblocks, bps,
+                       nseg, io->counts);
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, *io,
+                       seg_len, bps, (const uint64_t*)ctx->d_block_off);
+    LRC_HIP(hipGetLastError());
+    return LRC_OK;
+}
+
+int lrc_compact(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_compact_io* io,
+                uint64_t* out_total) {
+    if (!ctx || !io) return fail(LRC_ERR_INVALID_ARG, "lrc_compact: NULL argument");
+    if (out_total) *out_total = 0;
+    const uint64_t n = nseg * seg_len;
+    if (!n) return LRC_OK;
+    if (!io->t) return fail(LRC_ERR_INVALID_ARG, "lrc_compact: t is NULL");
+    LRC_HIP(hipSetDevice(ctx->device));
+    DevBuf t, p3, sem, ins, inc, cnt, op3, osem, oins, oinc, oidx;
+    lrc_compact_io d{};
+    auto up = [&](DevBuf& b, const void* src, size_t bytes, const void** dst) -> int {
+        LRC_HIP(hipMalloc(&b.p, bytes));
+        LRC_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+        *dst = b.p;
+        return LRC_OK;
+    };
+    int rc;
+    if ((rc = up(t, io->t, n * 4, (const void**)&d.t))) return rc;
+    if (io->point3 && (rc = up(p3, io->point3, n * 12, (const void**)&d.point3))) return rc;
+    if (io->sem && (rc = up(sem, io->sem, n * 2, (const void**)&d.sem))) return rc;
+    if (io->ins && (rc = up(ins, io->ins, n * 2, (const void**)&d.ins))) return rc;
+    if (io->incident_deg && (rc = up(inc, io->incident_deg, n * 8, (const void**)&d.incident_deg))) return rc;
+    LRC_HIP(hipMalloc(&cnt.p, nseg * 8)); d.counts = (uint64_t*)cnt.p;
+    if (io->out_point3) { LRC_HIP(hipMalloc(&op3.p, n * 12)); d.out_point3 = (float*)op3.p; }
+    if (io->out_sem) { LRC_HIP(hipMalloc(&osem.p, n * 2)); d.out_sem = (uint16_t*)osem.p; }
+    if (io->out_ins) { LRC_HIP(hipMalloc(&oins.p, n * 2)); d.out_ins = (uint16_t*)oins.p; }
+    if (io->out_incident_deg) { LRC_HIP(hipMalloc(&oinc.p, n * 8)); d.out_incident_deg = (double*)oinc.p; }
+    if (io->out_index) { LRC_HIP(hipMalloc(&oidx.p, n * 4)); d.out_index = (uint32_t*)oidx.p; }
+    if ((rc = lrc_compact_dev(ctx, nseg, seg_len, &d, nullptr))) return rc;
+    LRC_HIP(hipDeviceSynchronize());
+    std::vector<uint64_t> counts(nseg);
+    LRC_HIP(hipMemcpy(counts.data(), d.counts, nseg * 8, hipMemcpyDeviceToHost));
+    uint64_t K = 0;
+    for (uint64_t c : counts) K += c;
+    if (io->counts) std::memcpy(io->counts, counts.data(), nseg * 8);
+    if (out_total) *out_total = K;
+    if (K) {
+        if (io->out_point3) LRC_HIP(hipMemcpy(io->out_point3, d.out_point3, K * 12, hipMemcpyDeviceToHost));
+        if (io->out_sem) LRC_HIP(hipMemcpy(io->out_sem, d.out_sem, K * 2, hipMemcpyDeviceToHost));
+        if (io->out_ins) LRC_HIP(hipMemcpy(io->out_ins, d.out_ins, K * 2, hipMemcpyDeviceToHost));
+        if (io->out_incident_deg)
+            LRC_HIP(hipMemcpy(io->out_incident_deg, d.out_incident_deg, K * 8, hipMemcpyDeviceToHost));
+        if (io->out_index) LRC_HIP(hipMemcpy(io->out_index, d.out_index, K * 4, hipMemcpyDeviceToHost));
+    }
+    return LRC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// lrc_device.h -- device-side arithmetic of the ray-cast scan (gfx950 only).
+//
+// This header fixes the float32 expression trees that define a "hit" (DESIGN.md section 3).
+// oracle/lrc_oracle.c restates the same trees in plain C for the CPU; tests compare bit for bit.
+// The file is compiled with -ffp-contract=off: every fused multiply-add below is explicit.
+//
+// Reference semantics being reproduced:
+//   * closest hit, two-sided, tnear = 0 exclusive, tfar = +inf, parametric t along the given
+//     direction: the contract of open3d RaycastingScene.cast_rays, called at
+//     raycast_engine/raycast_engine_cpu.py:51 (Embree's Moeller-Trumbore intersector restated).
+//   * p = o + (d/|d|)*t in float32, separate mul and add:   raycast_engine_cpu.py:55-62
+//   * range filter and incident angle in float64:            raycast_engine_cpu.py:95-107
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lrcdev {
+
+#define LRC_DI __device__ __forceinline__
+
+constexpr float kTinyDir = 1e-30f;
+constexpr float kPadRelLo = 0.999755859375f;     // 1 - 2^-12
+constexpr float kPadRelHi = 1.000244140625f;     // 1 + 2^-12
+constexpr float kPadAbs   = 1.52587890625e-05f;  // 2^-16
+constexpr double kRadToDeg = 57.29577951308232;  // 180/pi, numpy's npy_rad2deg factor
+
+struct V3 { float x, y, z; };
+
+LRC_DI float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+LRC_DI float dot3(V3 a, V3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+LRC_DI V3 cross3(V3 a, V3 b) {
+    V3 r;
+    r.x = fma_(a.y, b.z, -(a.z * b.y));
+    r.y = fma_(a.z, b.x, -(a.x * b.z));
+    r.z = fma_(a.x, b.y, -(a.y * b.x));
+    return r;
+}
+LRC_DI V3 sub3(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+LRC_DI float xorsign(float x, uint32_t s) { return __uint_as_float(__float_as_uint(x) ^ s); }
+LRC_DI float min2(float a, float b) { return a < b ? a : b; }
+LRC_DI float max2(float a, float b) { return a > b ? a : b; }
+
+// Per-ray constants of the slab test.
+struct RaySlab { float ix, iy, iz, ox, oy, oz; };   // idir and o*idir
+
+LRC_DI float safe_inv(float d) {
+    float a = __builtin_fabsf(d);
+    float s = a < kTinyDir ? __builtin_copysignf(kTinyDir, d) : d;
+    return 1.0f / s;
+}
+LRC_DI RaySlab make_slab(V3 o, V3 d) {
+    RaySlab r;
+    r.ix = safe_inv(d.x); r.iy = safe_inv(d.y); r.iz = safe_inv(d.z);
+    r.ox = o.x * r.ix; r.oy = o.y * r.iy; r.oz = o.z * r.iz;
+    return r;
+}
+
+// Padded entry/exit parameters of the ray against the box [lo,hi].
+// Monotone in lo/hi, hence the interval of a box contains the interval of every box inside it.
+LRC_DI void slab_interval(const RaySlab& s, float lox, float loy, float loz, float hix, float hiy,
+                          float hiz, float& tn, float& tf) {
+    float t0x = fma_(lox, s.ix, -s.ox), t1x = fma_(hix, s.ix, -s.ox);
+    float t0y = fma_(loy, s.iy, -s.oy), t1y = fma_(hiy, s.iy, -s.oy);
+    float t0z = fma_(loz, s.iz, -s.oz), t1z = fma_(hiz, s.iz, -s.oz);
+    float nx = min2(t0x, t1x), fx = max2(t0x, t1x);
+    float ny = min2(t0y, t1y), fy = max2(t0y, t1y);
+    float nz = min2(t0z, t1z), fz = max2(t0z, t1z);
+    float n = max2(max2(nx, ny), max2(nz, 0.0f));
+    float f = min2(min2(fx, fy), fz);
+    tn = fma_(n, kPadRelLo, -kPadAbs);
+    tf = fma_(f, kPadRelHi, kPadAbs);
+}
+
+// Ray/triangle test.  Returns true and t when (o,d) hits the triangle record (v0,v1,v2,Ng):
+//   den = Ng.D != 0,  U = (C x D).e2,  V = (C x D).e1 (sign-corrected), U,V >= 0, U+V <= |den|,
+//   T = Ng.C (sign-corrected) > 0,  t = T/|den| finite and inside the padded slab interval of the
+//   triangle's own bounding box.
+LRC_DI bool tri_hit(V3 o, V3 d, const RaySlab& s, V3 v0, V3 v1, V3 v2, V3 ng, float& t_out) {
+    V3 e1 = sub3(v0, v1);
+    V3 e2 = sub3(v2, v0);
+    V3 c = sub3(v0, o);
+    V3 r = cross3(c, d);
+    float den = dot3(ng, d);
+    float aden = __builtin_fabsf(den);
+    uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+    float u = xorsign(dot3(r, e2), sgn);
+    float v = xorsign(dot3(r, e1), sgn);
+    float tt = xorsign(dot3(ng, c), sgn);
+    bool ok = (den != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= aden) & (tt > 0.0f);
+    if (!ok) return false;
+    float t = tt / aden;
+    float lox = min2(min2(v0.x, v1.x), v2.x), hix = max2(max2(v0.x, v1.x), v2.x);
+    float loy = min2(min2(v0.y, v1.y), v2.y), hiy = max2(max2(v0.y, v1.y), v2.y);
+    float loz = min2(min2(v0.z, v1.z), v2.z), hiz = max2(max2(v0.z, v1.z), v2.z);
+    float tn, tf;
+    slab_interval(s, lox, loy, loz, hix, hiy, hiz, tn, tf);
+    if (!((tn <= t) & (t <= tf) & (t < __builtin_inff()))) return false;
+    t_out = t;
+    return true;
+}
+
+}  // namespace lrcdev

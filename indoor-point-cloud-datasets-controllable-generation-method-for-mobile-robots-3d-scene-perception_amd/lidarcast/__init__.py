@@ -1,0 +1,14 @@
+"""lidarcast -- Python face of liblidarcast, the MI355X-native LiDAR ray-cast scan engine."""
+from ._capi import LIB_PATH, LRC_INVALID_PRIM, LidarcastError, load
+from .core import ATTRS, Context, DeviceHits, Scene
+
+__all__ = ["LIB_PATH", "LRC_INVALID_PRIM", "LidarcastError", "load", "ATTRS", "Context",
+           "DeviceHits", "Scene", "version", "device_count"]
+
+
+def version():
+    return load().lrc_version().decode()
+
+
+def device_count():
+    return int(load().lrc_device_count())

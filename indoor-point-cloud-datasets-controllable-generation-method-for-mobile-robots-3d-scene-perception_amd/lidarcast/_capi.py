@@ -1,0 +1,113 @@
+"""ctypes binding of liblidarcast (include/lidarcast.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950) and lives next to
+this package.  There is no fallback: if the library is missing, or there is no GPU, the calls
+raise -- the reference's caller catches engine construction errors itself
+(reference: s3dis_simulator.py:66-74).
+"""
+import ctypes as C
+import os
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "liblidarcast.so")
+
+LRC_OK = 0
+LRC_ERR_INVALID_ARG = -1
+LRC_ERR_NO_DEVICE = -2
+LRC_ERR_HIP = -3
+LRC_ERR_OOM = -4
+LRC_ERR_INTERNAL = -5
+LRC_INVALID_PRIM = 0xFFFFFFFF
+
+# every symbol include/lidarcast.h declares (tests check that the library exports all of them)
+SYMBOLS = (
+    "lrc_version", "lrc_last_error", "lrc_device_count",
+    "lrc_ctx_create", "lrc_ctx_destroy", "lrc_ctx_synchronize",
+    "lrc_scene_create", "lrc_scene_destroy", "lrc_scene_get_info", "lrc_scene_export_bvh",
+    "lrc_scene_get_counters",
+    "lrc_cast", "lrc_cast_dev", "lrc_scan_poses", "lrc_scan_poses_dev",
+    "lrc_compact", "lrc_compact_dev",
+)
+
+
+class LrcHits(C.Structure):
+    _fields_ = [("t", C.c_void_p), ("prim", C.c_void_p), ("normal3", C.c_void_p),
+                ("point3", C.c_void_p), ("sem", C.c_void_p), ("ins", C.c_void_p),
+                ("incident_deg", C.c_void_p)]
+
+
+class LrcSceneInfo(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint64), ("num_triangles", C.c_uint64),
+                ("num_nodes", C.c_uint64), ("num_leaves", C.c_uint64), ("num_slots", C.c_uint64),
+                ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32),
+                ("device_bytes", C.c_uint64), ("build_ms", C.c_double), ("upload_ms", C.c_double),
+                ("bounds_lo", C.c_float * 3), ("bounds_hi", C.c_float * 3)]
+
+
+class LrcCompactIO(C.Structure):
+    _fields_ = [("t", C.c_void_p), ("point3", C.c_void_p), ("sem", C.c_void_p), ("ins", C.c_void_p),
+                ("incident_deg", C.c_void_p), ("counts", C.c_void_p), ("out_point3", C.c_void_p),
+                ("out_sem", C.c_void_p), ("out_ins", C.c_void_p), ("out_incident_deg", C.c_void_p),
+                ("out_index", C.c_void_p)]
+
+
+_lib = None
+
+
+def load():
+    """Load liblidarcast.so once; raise RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"liblidarcast.so not found at {LIB_PATH}: build it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            f"This engine has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, dbl, i32 = C.c_void_p, C.c_uint64, C.c_double, C.c_int
+    lib.lrc_version.restype = C.c_char_p
+    lib.lrc_version.argtypes = []
+    lib.lrc_last_error.restype = C.c_char_p
+    lib.lrc_last_error.argtypes = []
+    lib.lrc_device_count.restype = i32
+    lib.lrc_device_count.argtypes = []
+    sig = {
+        "lrc_ctx_create": [i32, C.POINTER(vp)],
+        "lrc_ctx_destroy": [vp],
+        "lrc_ctx_synchronize": [vp],
+        "lrc_scene_create": [vp, vp, u64, vp, u64, vp, vp, C.POINTER(vp)],
+        "lrc_scene_destroy": [vp],
+        "lrc_scene_get_info": [vp, C.POINTER(LrcSceneInfo)],
+        "lrc_scene_export_bvh": [vp, vp, vp],
+        "lrc_scene_get_counters": [vp, C.POINTER(u64), C.POINTER(u64)],
+        "lrc_cast": [vp, vp, u64, vp, dbl, C.POINTER(LrcHits)],
+        "lrc_cast_dev": [vp, vp, u64, vp, dbl, C.POINTER(LrcHits), vp],
+        "lrc_scan_poses": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcHits)],
+        "lrc_scan_poses_dev": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcHits), vp],
+        "lrc_compact": [vp, u64, u64, C.POINTER(LrcCompactIO), C.POINTER(u64)],
+        "lrc_compact_dev": [vp, u64, u64, C.POINTER(LrcCompactIO), vp],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = i32
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+class LidarcastError(RuntimeError):
+    """A liblidarcast call failed (HIP error, no device, out of memory)."""
+
+
+def check(rc, what):
+    """Map a C status to the Python exception the reference interface promises."""
+    if rc == LRC_OK:
+        return
+    msg = load().lrc_last_error().decode("utf-8", "replace")
+    text = f"{what} failed ({rc}): {msg}"
+    if rc == LRC_ERR_INVALID_ARG:
+        raise ValueError(text)
+    if rc == LRC_ERR_OOM:
+        raise MemoryError(text)
+    raise LidarcastError(text)

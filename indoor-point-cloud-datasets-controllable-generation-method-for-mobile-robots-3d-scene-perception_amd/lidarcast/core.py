@@ -1,0 +1,233 @@
+"""Context / Scene objects over the C ABI.
+
+Host-array methods (numpy in, numpy out) go through lrc_cast / lrc_scan_poses / lrc_compact.
+Device methods (torch CUDA tensors; torch is only the allocator and the stream) go through the
+*_dev entry points and never leave HBM.
+
+Reference interface being served: raycast_engine/raycast_engine.py:16-61 (engine ABC) and the
+Open3D calls at raycast_engine/raycast_engine_cpu.py:46-53.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import LrcCompactIO, LrcHits, LrcSceneInfo, check
+
+ATTRS = ("t", "prim", "normal3", "point3", "sem", "ins", "incident_deg")
+_NP_SPEC = {
+    "t": (np.float32, ()), "prim": (np.uint32, ()), "normal3": (np.float32, (3,)),
+    "point3": (np.float32, (3,)), "sem": (np.uint16, ()), "ins": (np.uint16, ()),
+    "incident_deg": (np.float64, ()),
+}
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One HIP device.  Raises (LidarcastError) when there is no GPU or the library is missing."""
+
+    def __init__(self, device=0):
+        self._lib = _capi.load()
+        h = C.c_void_p()
+        check(self._lib.lrc_ctx_create(int(device), C.byref(h)), "lrc_ctx_create")
+        self._h = h
+        self.device = int(device)
+
+    def synchronize(self):
+        check(self._lib.lrc_ctx_synchronize(self._h), "lrc_ctx_synchronize")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lrc_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- compaction -----------------------------------------------------------------------------
+    def compact(self, t, seg_len, point3=None, sem=None, ins=None, incident_deg=None,
+                want_index=False):
+        """Stable compaction of finite-t entries; returns dict(counts, point3, sem, ins, ...)."""
+        t = np.ascontiguousarray(t, dtype=np.float32).reshape(-1)
+        seg_len = int(seg_len)
+        n = t.size
+        if seg_len <= 0 or n % seg_len:
+            raise ValueError("t.size must be a multiple of seg_len")
+        nseg = n // seg_len
+        io = LrcCompactIO()
+        keep = [t]
+        io.t = t.ctypes.data
+        counts = np.zeros(nseg, dtype=np.uint64)
+        io.counts = counts.ctypes.data
+        outs = {}
+
+        def wire(name, arr, dtype, tail):
+            if arr is None:
+                return
+            a = np.ascontiguousarray(arr, dtype=dtype).reshape((n,) + tail)
+            keep.append(a)
+            setattr(io, name, a.ctypes.data)
+            o = np.empty((n,) + tail, dtype=dtype)
+            outs[name] = o
+            setattr(io, "out_" + name, o.ctypes.data)
+
+        wire("point3", point3, np.float32, (3,))
+        wire("sem", sem, np.uint16, ())
+        wire("ins", ins, np.uint16, ())
+        wire("incident_deg", incident_deg, np.float64, ())
+        if want_index:
+            outs["index"] = np.empty(n, dtype=np.uint32)
+            io.out_index = outs["index"].ctypes.data
+        total = C.c_uint64(0)
+        check(self._lib.lrc_compact(self._h, nseg, seg_len, C.byref(io), C.byref(total)), "lrc_compact")
+        k = int(total.value)
+        res = {"counts": counts.astype(np.int64), "total": k}
+        for name, o in outs.items():
+            res[name] = o[:k]
+        return res
+
+    def compact_dev(self, nseg, seg_len, io, stream=0):
+        """io: LrcCompactIO filled with device pointers."""
+        check(self._lib.lrc_compact_dev(self._h, int(nseg), int(seg_len), C.byref(io),
+                                        C.c_void_p(int(stream))), "lrc_compact_dev")
+
+
+class DeviceHits:
+    """Fixed-stride per-ray records in HBM (torch tensors), n entries."""
+
+    _TORCH = {"t": "float32", "prim": "int32", "normal3": "float32", "point3": "float32",
+              "sem": "int16", "ins": "int16", "incident_deg": "float64"}
+
+    def __init__(self, n, device, want=("t", "prim", "normal3", "point3", "sem", "ins")):
+        import torch
+        self.n = int(n)
+        self.want = tuple(want)
+        self.tensors = {}
+        for a in self.want:
+            shape = (self.n, 3) if a.endswith("3") else (self.n,)
+            self.tensors[a] = torch.empty(shape, dtype=getattr(torch, self._TORCH[a]), device=device)
+        self.struct = LrcHits()
+        for a in self.want:
+            setattr(self.struct, a, self.tensors[a].data_ptr())
+
+    def __getitem__(self, k):
+        return self.tensors[k]
+
+    def bytes_per_ray(self):
+        return sum(t.element_size() * (3 if a.endswith("3") else 1) for a, t in self.tensors.items())
+
+
+class Scene:
+    """A triangle mesh and its BVH, resident in HBM.  Built once, cast many times."""
+
+    def __init__(self, ctx, vertices, triangles, tri_sem=None, tri_ins=None):
+        self._lib = _capi.load()
+        self.ctx = ctx
+        v = np.ascontiguousarray(np.asarray(vertices), dtype=np.float32)    # the one f64->f32 narrowing
+        f = np.asarray(triangles)
+        if v.ndim != 2 or v.shape[1] != 3:
+            raise ValueError("vertices must be (V, 3)")
+        if f.size == 0:
+            f = np.zeros((0, 3), dtype=np.uint32)
+        if f.ndim != 2 or f.shape[1] != 3:
+            raise ValueError("triangles must be (T, 3)")
+        if f.size and (f.min() < 0):
+            raise ValueError("negative triangle index")
+        f = np.ascontiguousarray(f, dtype=np.uint32)
+        sem = None if tri_sem is None else np.ascontiguousarray(tri_sem, dtype=np.uint16)
+        ins = None if tri_ins is None else np.ascontiguousarray(tri_ins, dtype=np.uint16)
+        for lab in (sem, ins):
+            if lab is not None and lab.shape != (f.shape[0],):
+                raise ValueError("per-triangle labels must have shape (T,)")
+        h = C.c_void_p()
+        check(self._lib.lrc_scene_create(ctx._h, _ptr(v), v.shape[0], _ptr(f), f.shape[0],
+                                         _ptr(sem), _ptr(ins), C.byref(h)), "lrc_scene_create")
+        self._h = h
+        self.num_vertices, self.num_triangles = v.shape[0], f.shape[0]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lrc_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def info(self):
+        inf = LrcSceneInfo()
+        check(self._lib.lrc_scene_get_info(self._h, C.byref(inf)), "lrc_scene_get_info")
+        d = {k: getattr(inf, k) for k, _ in LrcSceneInfo._fields_ if not k.startswith("bounds")}
+        d["bounds_lo"] = tuple(inf.bounds_lo)
+        d["bounds_hi"] = tuple(inf.bounds_hi)
+        return d
+
+    def counters(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(self._lib.lrc_scene_get_counters(self._h, C.byref(a), C.byref(b)), "lrc_scene_get_counters")
+        return int(a.value), int(b.value)
+
+    def export_bvh(self):
+        inf = self.info
+        nodes = np.zeros((inf["num_nodes"], 16), dtype=np.float32)
+        slot_prim = np.zeros(inf["num_slots"], dtype=np.uint32)
+        check(self._lib.lrc_scene_export_bvh(self._h, _ptr(nodes), _ptr(slot_prim)), "lrc_scene_export_bvh")
+        return nodes, slot_prim
+
+    # ---- host arrays ----------------------------------------------------------------------------
+    @staticmethod
+    def _alloc(n, want):
+        outs, st = {}, LrcHits()
+        for a in want:
+            if a not in _NP_SPEC:
+                raise ValueError(f"unknown hit attribute {a!r}")
+            dt, tail = _NP_SPEC[a]
+            outs[a] = np.empty((n,) + tail, dtype=dt)
+            setattr(st, a, outs[a].ctypes.data)
+        return outs, st
+
+    def cast(self, rays, center=None, max_range=np.inf, want=ATTRS):
+        """rays (N,6) float32 -> dict of per-ray arrays (Open3D cast_rays + numpy post-processing)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        if rays.ndim != 2 or rays.shape[1] != 6:
+            raise ValueError("rays must be a (N, 6) array.")
+        n = rays.shape[0]
+        outs, st = self._alloc(n, want)
+        c = None if center is None else np.ascontiguousarray(center, dtype=np.float64).reshape(3)
+        check(self._lib.lrc_cast(self._h, _ptr(rays), n, _ptr(c), float(max_range), C.byref(st)), "lrc_cast")
+        return outs
+
+    def scan_poses(self, poses, dirs, max_range, want=ATTRS):
+        """poses (P,4,4) f64, dirs (N,3) f64 sensor-frame -> dict of (P*N, ...) arrays."""
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 16)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float64)
+        if dirs.ndim != 2 or dirs.shape[1] != 3:
+            raise ValueError("dirs must be (N, 3)")
+        P, N = poses.shape[0], dirs.shape[0]
+        outs, st = self._alloc(P * N, want)
+        check(self._lib.lrc_scan_poses(self._h, _ptr(poses), P, _ptr(dirs), N, float(max_range),
+                                       C.byref(st)), "lrc_scan_poses")
+        return outs
+
+    # ---- device tensors -------------------------------------------------------------------------
+    def cast_dev(self, rays_t, hits, center=None, max_range=np.inf, stream=0):
+        c = None if center is None else np.ascontiguousarray(center, dtype=np.float64).reshape(3)
+        check(self._lib.lrc_cast_dev(self._h, C.c_void_p(rays_t.data_ptr()), rays_t.shape[0], _ptr(c),
+                                     float(max_range), C.byref(hits.struct), C.c_void_p(int(stream))),
+              "lrc_cast_dev")
+
+    def scan_poses_dev(self, poses_t, dirs_t, hits, max_range, stream=0):
+        P, N = poses_t.shape[0], dirs_t.shape[0]
+        check(self._lib.lrc_scan_poses_dev(self._h, C.c_void_p(poses_t.data_ptr()), P,
+                                           C.c_void_p(dirs_t.data_ptr()), N, float(max_range),
+                                           C.byref(hits.struct), C.c_void_p(int(stream))),
+              "lrc_scan_poses_dev")

@@ -1,0 +1,45 @@
+"""pytest wiring: put the product package root on sys.path (it mirrors the reference's top-level
+layout: ``raycast_engine``, ``lidar``, ``containers``, ``trajectory``), register the gpu marker."""
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "indoor-point-cloud-datasets-controllable-generation-method-for-mobile-"
+                         "robots-3d-scene-perception_amd")
+for p in (PKG, REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import lidarcast
+        return lidarcast.device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+    import numpy as np
+    g = os.path.join(REPO, "tests", "golden")
+    arrays = np.load(os.path.join(g, "lidar_golden.npz"))
+    with open(os.path.join(g, "lidar_golden.json")) as f:
+        meta = json.load(f)
+    return arrays, meta

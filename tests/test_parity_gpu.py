@@ -1,0 +1,296 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Bars: hit mask, surviving ray indices and triangle ids bit-exact; range t
+bit-exact (the allowed tolerance is 1e-5 m; the implementation meets 0 ulp and the tests assert it);
+float64 incident angles within 1e-9 degree (device acos vs numpy's libm).
+"""
+import numpy as np
+import pytest
+
+from helpers import (assert_bit_equal, pose, random_rays, random_soup, sensor_32x2048, sensor_8x512,
+                     sensor_small)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lidarcast
+    c = lidarcast.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from raycast_engine import RaycastEngineGPU
+    e = RaycastEngineGPU()
+    yield e
+    e.clear_cache()
+
+
+def _scene_pair(ctx, mesh):
+    import lidarcast
+    from oracle.c_oracle import OracleMesh
+    sem = getattr(mesh, "triangle_sem", None)
+    ins = getattr(mesh, "triangle_ins", None)
+    return lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, sem, ins), OracleMesh(mesh.vertices, mesh.triangles)
+
+
+def _check_cast(scene, om, rays, brute):
+    out = scene.cast(rays)
+    t, prim = om.brute(rays) if brute else om.cast(rays, threads=8)
+    assert_bit_equal(out["t"], t, "t")
+    assert_bit_equal(out["prim"], prim, "prim")
+    assert_bit_equal(out["normal3"], om.normals(prim), "normal")
+    return out, t, prim
+
+
+@pytest.mark.parametrize("seed,n_tris", [(0, 1), (1, 7), (2, 300), (3, 5000)])
+def test_soup_vs_brute_force(ctx, seed, n_tris):
+    from lidarcast.synth import TriangleMesh
+    v, f = random_soup(n_tris, seed)
+    scene, om = _scene_pair(ctx, TriangleMesh(v, f))
+    rays = random_rays(3000, -5, 5, seed + 10)
+    out, t, prim = _check_cast(scene, om, rays, brute=True)
+    if n_tris >= 300:
+        assert 0.05 < np.isfinite(t).mean() < 1.0
+
+
+def test_room_vs_brute_force_and_bvh(ctx):
+    from lidarcast import synth
+    mesh = synth.make_room(size=(3, 2.5, 2), num_boxes=3, seed=11, cell=0.05)
+    scene, om = _scene_pair(ctx, mesh)
+    rays = random_rays(4000, 0.2, 1.8, 5)
+    out, t, prim = _check_cast(scene, om, rays, brute=True)
+    t2, prim2 = om.cast(rays)
+    assert_bit_equal(t2, t, "oracle bvh vs brute")
+    assert_bit_equal(prim2, prim)
+    assert np.isfinite(t).mean() > 0.99
+    # labels are those of the hit triangle
+    hit = prim != 0xFFFFFFFF
+    assert np.array_equal(out["sem"][hit], mesh.triangle_sem[prim[hit]])
+    assert np.array_equal(out["ins"][hit], mesh.triangle_ins[prim[hit]])
+    assert not out["sem"][~hit].any() and not out["ins"][~hit].any()
+
+
+def test_known_answers(ctx):
+    from lidarcast import synth
+    # quad at z = 2: straight up hits at t = 2 exactly, point (0.25, 0.25, 2)
+    scene, om = _scene_pair(ctx, synth.quad(z=2.0))
+    rays = np.array([[0.25, 0.25, 0, 0, 0, 1], [0.25, 0.25, 0, 0, 0, -1], [5, 5, 0, 0, 0, 1],
+                     [0.25, 0.25, 0, 0, 0, 2], [0.25, 0.25, 2.0, 0, 0, 1]], dtype=np.float32)
+    out = scene.cast(rays)
+    assert out["t"][0] == 2.0 and np.isinf(out["t"][1]) and np.isinf(out["t"][2])
+    assert out["t"][3] == 1.0                      # t is parametric along the given direction
+    assert np.isinf(out["t"][4])                   # tnear = 0 is exclusive: origin on the surface
+    assert np.allclose(out["point3"][0], [0.25, 0.25, 2.0]) and np.allclose(out["point3"][3], [0.25, 0.25, 2.0])
+    assert np.array_equal(out["normal3"][0], [0, 0, 1]) and out["prim"][1] == 0xFFFFFFFF
+    assert not out["point3"][1].any() and not out["normal3"][1].any()
+    # unit cube from the centre: every ray hits, t = 1 / max|d_k|
+    scene, om = _scene_pair(ctx, synth.unit_cube())
+    rays = random_rays(5000, 0, 0, 3)
+    out, t, prim = _check_cast(scene, om, rays, brute=True)
+    expect = 1.0 / np.abs(rays[:, 3:].astype(np.float64)).max(axis=1)
+    assert np.isfinite(t).all() and np.abs(t - expect).max() < 1e-5
+
+
+def test_ties_edges_and_degenerates(ctx):
+    from lidarcast.synth import TriangleMesh
+    # two coincident quads (exact t ties -> smaller triangle row wins), a zero-area triangle, and rays
+    # aimed exactly at shared edges / vertices / along the surface
+    v = np.array([[-1, -1, 2], [1, -1, 2], [1, 1, 2], [-1, 1, 2],
+                  [-1, -1, 2], [1, -1, 2], [1, 1, 2], [-1, 1, 2],
+                  [0, 0, 1], [0, 0, 1], [0, 0, 1]], dtype=np.float64)
+    f = np.array([[4, 5, 6], [4, 6, 7], [0, 1, 2], [0, 2, 3], [8, 9, 10]], dtype=np.int32)
+    scene, om = _scene_pair(ctx, TriangleMesh(v, f))
+    g = np.linspace(-1, 1, 21)
+    X, Y = np.meshgrid(g, g)
+    tgt = np.stack([X.ravel(), Y.ravel(), np.full(X.size, 2.0)], 1)
+    o = np.array([0.1, -0.2, 0.0])
+    d = tgt - o
+    rays = np.concatenate([np.tile(o, (len(d), 1)), d], 1).astype(np.float32)
+    graze = np.array([[-2, 0, 2, 1, 0, 0], [0, 0, 2, 1, 1, 0], [-2, -2, 2, 1, 1, 0]], dtype=np.float32)
+    rays = np.concatenate([rays, graze])
+    out, t, prim = _check_cast(scene, om, rays, brute=True)
+    inside = np.isfinite(t[:len(d)])
+    assert inside.mean() > 0.9
+    assert set(np.unique(prim[:len(d)][inside])) <= {0, 1}      # rows 0/1 beat the coincident rows 2/3
+
+
+def test_empty_and_tiny_inputs(ctx):
+    import lidarcast
+    from lidarcast.synth import TriangleMesh, quad
+    scene = lidarcast.Scene(ctx, np.zeros((0, 3)), np.zeros((0, 3), np.int32))
+    out = scene.cast(random_rays(100, -1, 1, 0))
+    assert np.isinf(out["t"]).all() and (out["prim"] == 0xFFFFFFFF).all()
+    scene = lidarcast.Scene(ctx, quad().vertices, quad().triangles)
+    out = scene.cast(np.zeros((0, 6), np.float32))
+    assert out["t"].shape == (0,) and out["point3"].shape == (0, 3)
+    with pytest.raises(ValueError):
+        scene.cast(np.zeros((4, 5), np.float32))
+    with pytest.raises(ValueError):
+        lidarcast.Scene(ctx, np.zeros((3, 3)), np.array([[0, 1, 3]]))        # index out of range
+    with pytest.raises(ValueError):
+        lidarcast.Scene(ctx, np.full((3, 3), np.nan), np.array([[0, 1, 2]]))
+
+
+def test_bvh_invariants(ctx):
+    import lidarcast
+    from lidarcast import synth
+    mesh = synth.make_room(size=(3, 2, 2), num_boxes=3, seed=2, cell=0.04)
+    scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles)
+    nodes, slot_prim = scene.export_bvh()
+    info = scene.info
+    T = len(mesh.triangles)
+    assert sorted(slot_prim.tolist()) == list(range(T))
+    assert info["max_depth"] <= 31 and info["max_leaf_size"] <= 4
+    refs = nodes[:, 12:14].view(np.int32)
+    v32 = mesh.vertices.astype(np.float32)
+    tri_lo = v32[mesh.triangles].min(axis=1)
+    tri_hi = v32[mesh.triangles].max(axis=1)
+    seen = np.zeros(T, bool)
+    inner_seen = np.zeros(len(nodes), bool)
+    inner_seen[0] = True
+
+    def walk(ref, lo, hi, depth):
+        """returns exact bounds below ref; checks they equal the stored child box"""
+        if ref < 0:
+            enc = ~ref
+            first, cnt = enc >> 3, enc & 7
+            assert 1 <= cnt <= 4 and depth <= 31
+            ids = slot_prim[first:first + cnt]
+            assert not seen[ids].any()
+            seen[ids] = True
+            blo, bhi = tri_lo[ids].min(0), tri_hi[ids].max(0)
+        else:
+            assert not inner_seen[ref] or ref == 0
+            inner_seen[ref] = True
+            n = nodes[ref]
+            a = walk(int(refs[ref, 0]), n[0:3], n[3:6], depth + 1)
+            b = walk(int(refs[ref, 1]), n[6:9], n[9:12], depth + 1)
+            blo, bhi = np.minimum(a[0], b[0]), np.maximum(a[1], b[1])
+        if lo is not None:
+            assert np.array_equal(blo, lo) and np.array_equal(bhi, hi)     # exact, unpadded boxes
+        return blo, bhi
+
+    import sys
+    sys.setrecursionlimit(10000)
+    walk(0, None, None, 0)
+    assert seen.all() and inner_seen.all()
+
+
+# ---- configs C1/C2: 8 x 512 single pose in synth_A1_office ---------------------------------------
+@pytest.fixture(scope="module")
+def a1():
+    from lidarcast import synth
+    from oracle.c_oracle import OracleMesh
+    mesh = synth.make_scene("synth_A1_office")
+    return mesh, OracleMesh(mesh.vertices, mesh.triangles).build()
+
+
+def test_c2_8x512_single_pose_bit_exact(engine, a1):
+    from lidar import create_lidar
+    from oracle import np_oracle
+    mesh, om = a1
+    lidar = create_lidar(sensor_8x512(), pose(4.0, 3.0, 1.0))
+    pts, ang = engine.lidar_intersect_mesh(lidar, mesh)
+    ref_pts, ref_ang, ref_idx = np_oracle.lidar_intersect_mesh(om, lidar, threads=8, return_index=True)
+    assert pts.dtype == np.float32 and ang.dtype == np.float64
+    assert_bit_equal(pts, ref_pts, "points")
+    assert ang.shape == ref_ang.shape and np.abs(ang - ref_ang).max() < 1e-9
+    # per-ray view: hit mask, surviving indices, triangle ids, t
+    res = engine.cast_rays(lidar.get_rays(), mesh, center=lidar.pose[:3, 3], max_range=lidar.intrinsics.max_range)
+    assert np.array_equal(np.flatnonzero(res["t_hit"] != np.inf), ref_idx)
+    t, prim = om.cast(lidar.get_rays(), threads=8)
+    assert_bit_equal(res["t_hit"][ref_idx], t[ref_idx])
+    assert_bit_equal(res["primitive_ids"][ref_idx], prim[ref_idx])
+    assert len(pts) > 4000
+    # rays_intersect_mesh: same compaction without the range filter
+    p2 = engine.rays_intersect_mesh(rays=lidar.get_rays(), mesh=mesh)
+    assert_bit_equal(p2, np_oracle.rays_intersect_mesh(om, lidar.get_rays(), threads=8))
+
+
+def test_range_filter_strict_and_rotated_pose(engine, a1):
+    import dataclasses
+    from lidar import create_lidar
+    from oracle import np_oracle
+    mesh, om = a1
+    k = dataclasses.replace(sensor_8x512(), max_range=2.5)       # cuts through the hits
+    lidar = create_lidar(k, pose(1.7, 2.2, 1.3, yaw=0.7))
+    pts, ang = engine.lidar_intersect_mesh(lidar, mesh)
+    ref_pts, ref_ang = np_oracle.lidar_intersect_mesh(om, lidar, threads=8)
+    assert 0 < len(ref_pts) < 4096 * 0.9
+    assert_bit_equal(pts, ref_pts)
+    assert np.abs(ang - ref_ang).max() < 1e-9
+    k0 = dataclasses.replace(sensor_8x512(), max_range=0.05)     # removes everything
+    pts, ang = engine.lidar_intersect_mesh(create_lidar(k0, pose(4, 3, 1)), mesh)
+    assert pts.shape == (0, 3) and ang.shape == (0,) and ang.dtype == np.float64
+
+
+def test_dual_axis_seeded_noise(engine, a1):
+    from lidar import DualAxisLidarIntrinsics, create_lidar
+    from oracle import np_oracle
+    mesh, om = a1
+    k = DualAxisLidarIntrinsics.create_blk2go_dual_axis()
+    np.random.seed(0)
+    lidar = create_lidar(k, pose(4.0, 3.0, 1.0))
+    rays = lidar.get_rays()
+
+    class Frozen:                       # same rays for both engines
+        intrinsics, pose = k, lidar.pose
+        def get_rays(self):
+            return rays
+    pts, ang = engine.lidar_intersect_mesh(Frozen(), mesh)
+    ref_pts, ref_ang = np_oracle.lidar_intersect_mesh(om, Frozen(), threads=8)
+    assert rays.shape == (62739, 6)
+    assert_bit_equal(pts, ref_pts)
+    assert np.abs(ang - ref_ang).max() < 1e-9
+
+
+def test_scan_poses_matches_per_pose_calls(engine):
+    from lidar import create_lidar
+    from lidarcast import synth
+    from oracle.c_oracle import OracleMesh
+    from oracle import np_oracle
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=4, seed=5, cell=0.04)
+    om = OracleMesh(mesh.vertices, mesh.triangles).build()
+    k = sensor_small(lines=6, width=200, max_range=2.2)
+    poses = np.stack([pose(1.0 + 0.4 * i, 1.5, 1.0, yaw=0.0) for i in range(5)] + [pose(2.0, 1.4, 1.1, yaw=1.1)])
+    rec, N = engine.scan_poses(k, poses, mesh, want=("t", "prim", "point3", "incident_deg", "sem", "ins"))
+    assert N == 1200 and rec["t"].shape == (6, 1200)
+    for p in range(len(poses)):
+        lidar = create_lidar(k, poses[p])
+        ref_pts, ref_ang, ref_idx = np_oracle.lidar_intersect_mesh(om, lidar, threads=4, return_index=True)
+        keep = rec["t"][p] != np.inf
+        if p < 5:      # yaw = 0: in-kernel ray generation is bit-identical to the host generator
+            assert np.array_equal(np.flatnonzero(keep), ref_idx)
+            assert_bit_equal(rec["point3"][p][keep], ref_pts)
+            assert np.abs(rec["incident_deg"][p][keep] - ref_ang).max() < 1e-9
+        else:          # rotated: directions may differ by 1 ulp (BLAS vs in-kernel float64 order)
+            assert abs(int(keep.sum()) - len(ref_idx)) <= 2
+            common = np.intersect1d(np.flatnonzero(keep), ref_idx)
+            sel = np.isin(ref_idx, common)
+            assert np.abs(rec["point3"][p][common] - ref_pts[sel]).max() < 1e-4
+
+
+def test_compaction_matches_numpy(ctx):
+    rng = np.random.default_rng(0)
+    for nseg, seg_len in ((1, 1), (3, 1000), (5, 256), (2, 4097), (7, 63)):
+        n = nseg * seg_len
+        t = rng.uniform(0, 10, n).astype(np.float32)
+        t[rng.random(n) < 0.37] = np.inf
+        pts = rng.normal(size=(n, 3)).astype(np.float32)
+        sem = rng.integers(0, 13, n).astype(np.uint16)
+        ins = rng.integers(0, 60000, n).astype(np.uint16)
+        ang = rng.uniform(0, 90, n)
+        r = ctx.compact(t, seg_len, point3=pts, sem=sem, ins=ins, incident_deg=ang, want_index=True)
+        keep = np.isfinite(t)
+        assert r["total"] == keep.sum()
+        assert np.array_equal(r["counts"], keep.reshape(nseg, seg_len).sum(1))
+        assert_bit_equal(r["point3"], pts[keep])
+        assert np.array_equal(r["sem"], sem[keep]) and np.array_equal(r["ins"], ins[keep])
+        assert_bit_equal(r["incident_deg"], ang[keep])
+        assert np.array_equal(r["index"], np.tile(np.arange(seg_len), nseg)[keep].astype(np.uint32))
+    r = ctx.compact(np.full(300, np.inf, np.float32), 100, point3=np.zeros((300, 3), np.float32))
+    assert r["total"] == 0 and r["point3"].shape == (0, 3)

@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/s of the LiDAR ray-cast scan on MI355X (config C3 of BASELINE.md).
+
+One "step" = one pass of the hot path over the whole trajectory batch, inputs resident in HBM:
+  trace kernel (rays generated in-kernel from 64 poses x the 32x2048 direction table, BVH
+  traversal, hit write-back of t/prim/normal/point/sem/ins, range filter)  ->  stable compaction
+  into the scene cloud (np.vstack order)  ->  for N > 1, one RCCL all-gather of the clouds.
+Weak scaling: every rank scans its own 64 poses of a 64*N-pose trajectory over a replica of the scene.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the trace kernel with the algorithmic bytes per ray
+of SURVEY.md section 8(d); `cpu_baseline` times the CPU oracle (a restatement: Open3D/Embree, the
+reference's CPU path, is not installed) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "indoor-point-cloud-datasets-controllable-generation-method-for-mobile-"
+                         "robots-3d-scene-perception_amd")
+for p in (PKG, REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SCENE = "synth_A6_office2"
+POSES_PER_GPU = 64
+
+
+def bytes_per_ray(T, in_kernel_raygen=True):
+    """Algorithmic bytes per ray, SURVEY.md section 8(d): ray in (24, dropped when rays are generated
+    in-kernel) + hit record out (36) + one root-to-leaf descent of a binary BVH with <= 4 triangles per
+    leaf (64 B per level) + one 4-triangle leaf (144)."""
+    levels = math.ceil(math.log2(max(T, 8) / 4.0))
+    return (0 if in_kernel_raygen else 24) + 36 + 64 * levels + 144
+
+
+def c3_sensor():
+    import dataclasses
+    from lidar import Indoor8LineLidarIntrinsics
+    return dataclasses.replace(Indoor8LineLidarIntrinsics.create_dense_32line(), horizontal_res=2048)
+
+
+def c3_poses(rank, world):
+    """64 poses per rank on the straight line x = 1..4 m, y = 2, z = 1, yaw 0 (what an auto trajectory
+    looks like in the reference: pure translations at fixed height).  The 64*world poses of the whole
+    job are evenly spaced on that line; rank r owns the r-th contiguous block."""
+    from trajectory import line_trajectory, poses_from_waypoints
+    wps = line_trajectory((1.0, 2.0, 1.0), (4.0, 2.0, 1.0), POSES_PER_GPU * world)
+    return poses_from_waypoints(wps[rank * POSES_PER_GPU:(rank + 1) * POSES_PER_GPU])
+
+
+def cpu_baseline(mesh, sensor, poses, budget_s=20.0):
+    """Reference-faithful CPU figure: per pose, host ray generation + BVH rebuild (the reference rebuilds
+    the Embree scene on every call, raycast_engine_cpu.py:46-47) + cast + numpy post-processing, on all
+    host cores, for as many poses as fit the budget.  Also the build-once variant."""
+    from lidar import create_lidar
+    from oracle import np_oracle
+    from oracle.c_oracle import OracleMesh
+    cores = os.cpu_count() or 1
+    n_per = sensor.vertical_res * sensor.horizontal_res
+    t_start = time.perf_counter()
+    done, t_faithful = 0, 0.0
+    for p in range(len(poses)):
+        t0 = time.perf_counter()
+        om = OracleMesh(mesh.vertices, mesh.triangles).build()       # per-pose scene rebuild
+        lidar = create_lidar(sensor, poses[p])
+        np_oracle.lidar_intersect_mesh(om, lidar, threads=cores)
+        om.free()
+        t_faithful += time.perf_counter() - t0
+        done += 1
+        if time.perf_counter() - t_start > budget_s * 0.6 or done >= 8:
+            break
+    om = OracleMesh(mesh.vertices, mesh.triangles).build()
+    t0 = time.perf_counter()
+    done_once = 0
+    for p in range(len(poses)):
+        np_oracle.lidar_intersect_mesh(om, create_lidar(sensor, poses[p]), threads=cores)
+        done_once += 1
+        if time.perf_counter() - t0 > budget_s * 0.3 or done_once >= 16:
+            break
+    t_once = time.perf_counter() - t0
+    return {
+        "value": done * n_per / t_faithful, "unit": "rays/s", "cores": cores, "kind": "port",
+        "sample": f"{done} of {len(poses)} poses x {n_per} rays of the C3 workload, BVH rebuilt per pose "
+                  f"as the reference does; oracle/lrc_oracle.c (C, pthreads) + numpy post-processing",
+        "build_once_value": done_once * n_per / t_once,
+        "build_once_sample": f"{done_once} poses, BVH built once",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scene", default=SCENE)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import lidarcast
+    from lidarcast import synth
+    from lidarcast._capi import LrcCompactIO
+    from lidarcast.distributed import gather_cloud
+    from lidar import IndoorLidar
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- scene (replicated) and inputs, resident in HBM before the timed region ----
+    mesh = synth.make_scene(args.scene)
+    ctx = lidarcast.Context(local_rank)
+    scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
+    info = scene.info
+    sensor = c3_sensor()
+    poses = c3_poses(rank, world)
+    dirs = IndoorLidar(intrinsics=sensor, pose=np.eye(4)).sensor_directions()
+    P, N = poses.shape[0], dirs.shape[0]
+    n = P * N
+    d_poses = torch.from_numpy(poses.reshape(P, 16)).to(dev)
+    d_dirs = torch.from_numpy(dirs).to(dev)
+    hits = lidarcast.DeviceHits(n, dev, want=("t", "prim", "normal3", "point3", "sem", "ins"))
+    label = torch.empty(0)
+    out_pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    out_sem = torch.empty(n, dtype=torch.int16, device=dev)
+    out_ins = torch.empty(n, dtype=torch.int16, device=dev)
+    counts = torch.zeros(P, dtype=torch.int64, device=dev)
+    io = LrcCompactIO()
+    io.t, io.point3 = hits["t"].data_ptr(), hits["point3"].data_ptr()
+    io.sem, io.ins = hits["sem"].data_ptr(), hits["ins"].data_ptr()
+    io.counts, io.out_point3 = counts.data_ptr(), out_pts.data_ptr()
+    io.out_sem, io.out_ins = out_sem.data_ptr(), out_ins.data_ptr()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    k_events = []
+
+    def step(timed):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        scene.scan_poses_dev(d_poses, d_dirs, hits, sensor.max_range, stream)
+        if timed:
+            e1.record()
+            k_events.append((e0, e1))
+        ctx.compact_dev(P, N, io, stream)
+        if world > 1:
+            k = int(counts.sum().item())
+            lab = (out_sem[:k].to(torch.int32) & 0xFFFF) | (out_ins[:k].to(torch.int32) << 16)
+            return gather_cloud(out_pts[:k], lab, counts, n, dist)
+        return None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in k_events]))
+    hits_total = int(counts.sum().item())
+    total_rays = n * world * args.steps
+    value = total_rays / elapsed
+    bpr = bytes_per_ray(info["num_triangles"])
+    achieved = n * bpr / (kernel_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        res = {
+            "metric": "rays/sec (whole node), 32-line x 2048-azimuth sweep",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"C3: create_dense_32line x horizontal_res=2048 ({N} rays/pose) x {P} poses per GPU "
+                            f"(straight line, yaw 0) over {args.scene} (procedural stand-in for an S3DIS "
+                            f"Area_6 office mesh, 2 cm tessellation, T={info['num_triangles']})",
+                "rays_per_step_per_gpu": n, "hit_fraction": hits_total / n,
+                "bvh": {"nodes": info["num_nodes"], "depth": info["max_depth"],
+                        "build_ms": round(info["build_ms"], 1), "device_MB": round(info["device_bytes"] / 1e6, 1)},
+                "step": "in-kernel ray generation + BVH traversal + hit write-back (36 B/ray) + stable "
+                        "compaction" + (" + RCCL all-gather of the clouds" if world > 1 else ""),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "trace_kernel<true>", "kernel_ms": kernel_ms, "bytes_per_ray": bpr,
+                "rays_per_launch": n,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(mesh, sensor, poses)
+            res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

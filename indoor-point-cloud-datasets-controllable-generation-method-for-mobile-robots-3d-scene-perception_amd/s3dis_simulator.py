@@ -1,0 +1,108 @@
+"""Drop-in caller of the engines: the reference's S3DISSimulator scan stage
+(reference: s3dis_simulator.py:36-77 construction, :220-296 run_simulation).
+
+Scope: sensor + engine selection and the scan loop.  Scene loading takes a mesh object (anything with
+``.vertices`` / ``.triangles``) or a PLY path; trajectory planning, visualisation and NKSR
+reconstruction are not part of this package.
+
+``run_simulation`` keeps the reference's per-frame ScanQuality formulas, including two quirks of the
+reference loop that a drop-in must reproduce to give the same statistics (``bug_compatible=True``):
+the incident angles are overwritten with zeros (:266-269) and the range statistics are norms from the
+WORLD origin, not from the sensor (:283-284).
+"""
+import time
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from containers import RoomBounds, S3DISScene, S3DISSimFrame, S3DISSimScene, ScanQuality
+from lidar import (DualAxisLidarIntrinsics, Indoor8LineLidarIntrinsics, create_lidar)
+from raycast_engine import RaycastEngineCPU, RaycastEngineGPU
+from trajectory import Waypoint, poses_from_waypoints
+
+
+class S3DISSimulator:
+    def __init__(self, config: Dict[str, Any], use_dense_lidar: bool = False, use_blk2go: bool = False,
+                 bug_compatible: bool = True):
+        self.config = config
+        self.use_dense_lidar = use_dense_lidar
+        self.use_blk2go = use_blk2go
+        self.bug_compatible = bug_compatible
+        self.scene: Optional[S3DISScene] = None
+        self.lidar_config = None
+        self.raycast_engine = None
+        self._initialize_components()
+
+    def _initialize_components(self):
+        if self.use_blk2go:
+            self.lidar_config = DualAxisLidarIntrinsics.create_blk2go_dual_axis()
+        elif self.use_dense_lidar:
+            self.lidar_config = Indoor8LineLidarIntrinsics.create_dense_32line()
+        else:
+            self.lidar_config = Indoor8LineLidarIntrinsics.create_standard_8line()
+        # Both names are the HIP engine in this package; construction raises without a GPU.
+        use_gpu = self.config.get("raycast_engine", {}).get("use_gpu", False)
+        self.raycast_engine = RaycastEngineGPU() if use_gpu else RaycastEngineCPU()
+
+    def load_scene(self, scene, scene_name: Optional[str] = None) -> S3DISScene:
+        """scene: mesh object or path to a triangle-mesh PLY."""
+        if isinstance(scene, (str, bytes)) or hasattr(scene, "__fspath__"):
+            from lidarcast.ply import read_triangle_mesh
+            mesh = read_triangle_mesh(scene)
+            scene_name = scene_name or str(scene).rsplit("/", 1)[-1].rsplit(".", 1)[0]
+        else:
+            mesh = scene
+        if len(np.asarray(mesh.vertices)) == 0:
+            raise ValueError("Failed to load mesh: no vertices")
+        self.scene = S3DISScene(scene_name or "scene", mesh, RoomBounds.from_vertices(mesh.vertices))
+        return self.scene
+
+    # ---- the scan stage ---------------------------------------------------------------------------
+    def _quality(self, points, incident_angles, total_points_per_scan, room_volume) -> ScanQuality:
+        k = len(points)
+        ranges = np.linalg.norm(points, axis=1) if k > 0 else None     # from the world origin, as the reference
+        return ScanQuality(
+            coverage_ratio=k / total_points_per_scan, num_points=k,
+            incident_angle_mean=np.mean(incident_angles) if len(incident_angles) > 0 else 0,
+            incident_angle_std=np.std(incident_angles) if len(incident_angles) > 0 else 0,
+            scan_density=k / room_volume,
+            range_mean=np.mean(ranges) if k > 0 else 0, range_std=np.std(ranges) if k > 0 else 0)
+
+    def run_simulation(self, waypoints: List[Waypoint]) -> S3DISSimScene:
+        if self.scene is None:
+            raise ValueError("Scene not loaded. Call load_scene() first.")
+        if self.raycast_engine is None:
+            raise ValueError("Raycast engine is not initialized.")
+        mesh = self.scene.room_mesh
+        sim_scene = S3DISSimScene(scene_name=self.scene.scene_name, simulation_config=self.config, mesh=mesh,
+                                  s3dis_data_root=self.config.get("s3dis_data_root"),
+                                  area=self.config.get("area"), room=self.config.get("room"))
+        start = time.time()
+        total = self.lidar_config.get_total_points_per_scan()
+        volume = self.scene.room_bounds.get_volume()
+
+        batched = isinstance(self.lidar_config, Indoor8LineLidarIntrinsics) and \
+            self.lidar_config.vertical_degrees is not None and len(waypoints) > 0
+        if batched:
+            # every pose in one launch; rays generated in the kernel
+            rec, n = self.raycast_engine.scan_poses(self.lidar_config, poses_from_waypoints(waypoints), mesh,
+                                                    want=("t", "point3", "incident_deg", "sem", "ins"))
+        for i, wp in enumerate(waypoints):
+            if batched:
+                keep = rec["t"][i] != np.inf
+                points, angles = rec["point3"][i][keep], rec["incident_deg"][i][keep]
+                sem, ins = rec["sem"][i][keep], rec["ins"][i][keep]
+            else:
+                lidar = create_lidar(self.lidar_config, wp.to_pose_matrix())
+                res = self.raycast_engine.cast_rays(lidar.get_rays(), mesh, center=lidar.pose[:3, 3],
+                                                    max_range=self.lidar_config.max_range)
+                keep = res["t_hit"] != np.inf
+                points, angles = res["points"][keep], res["incident_angles"][keep]
+                sem, ins = res["semantic"][keep], res["instance"][keep]
+            if self.bug_compatible:
+                angles = np.zeros(len(points))            # reference :266-269
+            q = self._quality(points, angles, total, volume)
+            sim_scene.append_frame(S3DISSimFrame(i, points, angles, q, semantic_labels=sem,
+                                                 instance_labels=ins))
+        sim_scene.compute_statistics(time.time() - start)
+        return sim_scene

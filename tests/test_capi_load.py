@@ -1,0 +1,52 @@
+"""CPU: the C-ABI library loads and exports every symbol include/lidarcast.h declares; the product
+fails loudly without a GPU (no compute calls are made here)."""
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def test_header_and_library_agree():
+    import lidarcast
+    from lidarcast import _capi
+    hdr = open(os.path.join(REPO, "include", "lidarcast.h")).read()
+    declared = set(re.findall(r"\b(lrc_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"lrc_hits", "lrc_compact_io", "lrc_scene_info"}
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    lib = lidarcast.load()
+    for name in declared:
+        assert hasattr(lib, name), f"liblidarcast.so does not export {name}"
+    assert lidarcast.version().startswith("lidarcast ")
+    assert os.path.dirname(lidarcast.LIB_PATH).endswith("_amd")          # in-tree build
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from lidarcast._capi import LrcCompactIO, LrcHits, LrcSceneInfo
+    assert C.sizeof(LrcHits) == 7 * 8
+    assert C.sizeof(LrcCompactIO) == 11 * 8
+    assert C.sizeof(LrcSceneInfo) == 5 * 8 + 2 * 4 + 8 + 2 * 8 + 6 * 4
+
+
+def test_no_gpu_means_loud_failure():
+    import lidarcast
+    if lidarcast.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(lidarcast.LidarcastError, match="no HIP device"):
+        lidarcast.Context(0)
+    from raycast_engine import RaycastEngineCPU, RaycastEngineGPU
+    for cls in (RaycastEngineGPU, RaycastEngineCPU):       # neither name hides a CPU fallback
+        with pytest.raises(RuntimeError):
+            cls()
+
+
+def test_product_never_imports_the_oracle():
+    from conftest import PKG
+    for root, _, files in os.walk(PKG):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(root, fn), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+                assert "liblrc_oracle" not in src and "orc_cast" not in src, fn

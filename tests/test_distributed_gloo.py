@@ -1,0 +1,97 @@
+"""CPU, world_size 2 and 3 over gloo: pose sharding + the single all-gather assemble the scene cloud
+in np.vstack order, independent of the number of ranks.  The per-rank scan is played by the CPU oracle
+here (this is the test harness; the product's ranks run the HIP scan)."""
+import hashlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, REPO
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scan_block(poses):
+    """oracle scan of a block of poses -> (points (K,3) f32, labels (K,) i32, counts (P,))"""
+    from lidar import create_lidar
+    from lidarcast import synth
+    from oracle import np_oracle
+    from oracle.c_oracle import OracleMesh
+    from helpers import sensor_small
+    mesh = synth.make_room(size=(3, 2.5, 2), num_boxes=2, seed=4, cell=0.1)
+    om = OracleMesh(mesh.vertices, mesh.triangles).build()
+    k = sensor_small(lines=3, width=40, max_range=1.6)
+    pts, labs, counts = [], [], []
+    for m in poses:
+        lidar = create_lidar(k, m)
+        p, _, idx = np_oracle.lidar_intersect_mesh(om, lidar, return_index=True)
+        _, prim = om.cast(lidar.get_rays())
+        lab = mesh.triangle_sem[prim[idx]].astype(np.int32) | (mesh.triangle_ins[prim[idx]].astype(np.int32) << 16)
+        pts.append(p)
+        labs.append(lab)
+        counts.append(len(p))
+    return (np.concatenate(pts) if pts else np.zeros((0, 3), np.float32),
+            np.concatenate(labs) if labs else np.zeros(0, np.int32), np.array(counts, np.int64), 120)
+
+
+def _all_poses(n=7):
+    from helpers import pose
+    return np.stack([pose(0.6 + 0.3 * i, 1.2, 1.0, 0.1 * i) for i in range(n)])
+
+
+def _worker(rank, world, port, q):
+    for p in (PKG, REPO, os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from lidarcast.distributed import gather_cloud, shard_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    poses = _all_poses()
+    b = shard_bounds(len(poses), world)
+    pts, labs, counts, n_per = _scan_block(poses[b[rank]:b[rank + 1]])
+    max_local = int(max(b[1:] - b[:-1])) * n_per
+    P, L, C = gather_cloud(torch.from_numpy(pts), torch.from_numpy(labs), torch.from_numpy(counts),
+                           max_local, dist)
+    h = hashlib.sha256(P.numpy().tobytes() + L.numpy().tobytes() + C.numpy().tobytes()).hexdigest()
+    q.put((rank, h, int(P.shape[0])))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gathered_cloud_is_rank_count_independent(world):
+    pts, labs, counts, _ = _scan_block(_all_poses())
+    want = hashlib.sha256(pts.tobytes() + labs.tobytes() + counts.tobytes()).hexdigest()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(pts) > 100
+    for rank, h, k in got:
+        assert k == len(pts) and h == want, f"rank {rank} assembled a different cloud"
+
+
+def test_shard_bounds():
+    from lidarcast.distributed import shard_bounds
+    assert shard_bounds(64, 8).tolist() == list(range(0, 65, 8))
+    assert shard_bounds(7, 3).tolist() == [0, 3, 5, 7]
+    assert shard_bounds(2, 4).tolist() == [0, 1, 2, 2, 2]
+    assert shard_bounds(0, 2).tolist() == [0, 0, 0]

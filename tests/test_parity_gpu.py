@@ -297,3 +297,55 @@ def test_compaction_matches_numpy(ctx):
         assert np.array_equal(r["index"], np.tile(np.arange(seg_len), nseg)[keep].astype(np.uint32))
     r = ctx.compact(np.full(300, np.inf, np.float32), 100, point3=np.zeros((300, 3), np.float32))
     assert r["total"] == 0 and r["point3"].shape == (0, 3)
+
+
+def test_simulator_scan_stage(tmp_path):
+    """S3DISSimulator.run_simulation (batched HIP scan) against the reference loop restated with the oracle."""
+    import s3dis_simulator
+    from containers import read_labeled_ply
+    from lidar import create_lidar
+    from lidarcast import synth
+    from oracle import np_oracle
+    from oracle.c_oracle import OracleMesh
+    from trajectory import line_trajectory
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=4, seed=5, cell=0.05)
+    om = OracleMesh(mesh.vertices, mesh.triangles).build()
+    sim = s3dis_simulator.S3DISSimulator({"raycast_engine": {"use_gpu": True}})
+    sim.load_scene(mesh, "room")
+    wps = line_trajectory((1.0, 1.5, 1.0), (3.0, 1.5, 1.0), 4)
+    scene = sim.run_simulation(wps)
+    assert scene.get_total_frames() == 4
+    total = sim.lidar_config.get_total_points_per_scan()
+    vol = sim.scene.room_bounds.get_volume()
+    sems = []
+    for i, wp in enumerate(wps):
+        lidar = create_lidar(sim.lidar_config, wp.to_pose_matrix())
+        ref_pts, _, idx = np_oracle.lidar_intersect_mesh(om, lidar, threads=8, return_index=True)
+        f = scene.frames[i]
+        assert_bit_equal(f.points, ref_pts)
+        assert not f.incident_angles.any()                       # reference quirk, s3dis_simulator.py:266-269
+        q = f.scan_quality
+        assert q.num_points == len(ref_pts) and q.coverage_ratio == len(ref_pts) / total
+        assert q.scan_density == len(ref_pts) / vol
+        assert q.range_mean == np.mean(np.linalg.norm(ref_pts, axis=1))      # from the world origin
+        _, prim = om.cast(lidar.get_rays(), threads=8)
+        assert np.array_equal(f.semantic_labels, mesh.triangle_sem[prim[idx]])
+        sems.append(f.semantic_labels)
+    scene.save_results(tmp_path)
+    rec = read_labeled_ply(tmp_path / "combined_pointcloud_with_label.ply")
+    assert len(rec) == scene.get_total_points() and np.array_equal(rec["sem"], np.concatenate(sems))
+    # the dual-axis sensor goes pose by pose through cast_rays
+    sim2 = s3dis_simulator.S3DISSimulator({"raycast_engine": {"use_gpu": True}}, use_blk2go=True)
+    sim2.load_scene(mesh, "room")
+    np.random.seed(3)
+    sc2 = sim2.run_simulation(wps[:2])
+    np.random.seed(3)
+    for i in range(2):
+        lidar = create_lidar(sim2.lidar_config, wps[i].to_pose_matrix())
+        rays = lidar.get_rays()
+        class Frozen:
+            intrinsics, pose = sim2.lidar_config, lidar.pose
+            def get_rays(self):
+                return rays
+        ref_pts, _ = np_oracle.lidar_intersect_mesh(om, Frozen(), threads=8)
+        assert_bit_equal(sc2.frames[i].points, ref_pts)

@@ -264,7 +264,7 @@ void build_bvh(const float* verts3, uint64_t V, const uint32_t* tris3, uint64_t 
     }
 
     // ---- triangle records in slot (leaf) order ----
-    o.tri_rec.resize(T * kTriFloats);
+    o.tri_rec.assign((T + kMaxLeaf - 1) * kTriFloats, 0.0f);   // padded: leaf-wide reads may overrun a short last leaf
     o.slot_prim.resize(T);
     o.slot_label.resize(T);
     for (uint64_t s = 0; s < T; ++s) {

@@ -102,11 +102,16 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nwg) {
     return base + (b >> 3);
 }
 
-__device__ __forceinline__ V3 ld3(const float4 a) { return V3{a.x, a.y, a.z}; }
+struct alignas(16) F4 { float x, y, z, w; };                       // plain 16-byte record (loads as dwordx4)
+typedef __attribute__((address_space(4))) const float cfloat;      // constant address space: uniform loads become s_load
+__device__ __forceinline__ F4 ld_uniform(const float4* gp) {
+    cfloat* c = (cfloat*)gp;
+    return F4{c[0], c[1], c[2], c[3]};
+}
 
-template <bool GEN>
+template <bool GEN, int LEAFW, bool UNI>
 __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams p) {
-    __shared__ int s_stack[kStack * kBlock];
+    extern __shared__ int s_stack[];   // [stack depth][kBlock]: one column per lane, conflict free
     const uint32_t tid = threadIdx.x;
     const uint64_t gid = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * kBlock + tid;
     if (gid >= p.total) return;
@@ -143,49 +148,77 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams p) {
     if (p.num_nodes) {
         int sp = 0;
         int ref = 0;   // root
+        // one inner-node step: test both child boxes, descend into the nearer hit child, push the other;
+        // nothing hit -> pop, or (stack empty) continue with the empty leaf so that the outer loop ends
+        auto step = [&](const F4 q0, const F4 q1, const F4 q2, const F4 q3) {
+            float n0, f0, n1, f1;
+            slab_interval(sl, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, n0, f0);
+            slab_interval(sl, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, n1, f1);
+            const bool h0 = (n0 <= f0) & (n0 <= tbest);
+            const bool h1 = (n1 <= f1) & (n1 <= tbest);
+            const int r0 = __float_as_int(q3.x), r1 = __float_as_int(q3.y);
+            if (h0 & h1) {
+                const bool first0 = n0 <= n1;
+                s_stack[sp * kBlock + tid] = first0 ? r1 : r0;
+                ++sp;
+                ref = first0 ? r0 : r1;
+            } else if (h0) {
+                ref = r0;
+            } else if (h1) {
+                ref = r1;
+            } else if (sp == 0) {
+                ref = ~0;   // empty leaf
+            } else {
+                --sp;
+                ref = s_stack[sp * kBlock + tid];
+            }
+        };
         while (true) {
             // descend inner nodes
             while (ref >= 0) {
-                const float4* n = p.nodes + (size_t)ref * 4;
-                const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-                float n0, f0, n1, f1;
-                slab_interval(sl, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, n0, f0);
-                slab_interval(sl, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, n1, f1);
-                const bool h0 = (n0 <= f0) & (n0 <= tbest);
-                const bool h1 = (n1 <= f1) & (n1 <= tbest);
-                const int r0 = __float_as_int(q3.x), r1 = __float_as_int(q3.y);
-                if (h0 & h1) {
-                    const bool first0 = n0 <= n1;
-                    s_stack[sp * kBlock + tid] = first0 ? r1 : r0;
-                    ++sp;
-                    ref = first0 ? r0 : r1;
-                } else if (h0) {
-                    ref = r0;
-                } else if (h1) {
-                    ref = r1;
-                } else {
-                    if (sp == 0) goto done;
-                    --sp;
-                    ref = s_stack[sp * kBlock + tid];
+                if (UNI) {
+                    // Neighbouring rays walk the top of the tree in lock step.  When every active lane
+                    // of the wave wants the same node, fetch it once through the scalar cache into
+                    // SGPRs (s_load) instead of 64 identical 64-byte vector loads through the L1.
+                    const int uref = __builtin_amdgcn_readfirstlane(ref);
+                    if (__builtin_amdgcn_ballot_w64(ref != uref) == 0ull) {
+                        const float4* n = p.nodes + (size_t)uref * 4;
+                        step(ld_uniform(n), ld_uniform(n + 1), ld_uniform(n + 2), ld_uniform(n + 3));
+                        continue;
+                    }
                 }
+                const F4* n = (const F4*)(p.nodes + (size_t)ref * 4);
+                step(n[0], n[1], n[2], n[3]);
             }
             // leaf
             {
                 const uint32_t enc = (uint32_t)(~ref);
                 const uint32_t first = enc >> 3, cnt = enc & 7u;
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    const uint32_t slot = first + k;
-                    const float4* tr = p.tris + (size_t)slot * 3;
-                    const float4 a = tr[0], b = tr[1], c = tr[2];
-                    const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
-                    float t;
-                    if (tri_hit(o, d, sl, v0, v1, v2, ng, t)) {
-                        if (t < tbest) {
-                            tbest = t; best_slot = slot; best_prim = 0xFFFFFFFFu;
-                        } else if (t == tbest) {
-                            if (best_prim == 0xFFFFFFFFu) best_prim = p.slot_prim[best_slot];
-                            const uint32_t pr = p.slot_prim[slot];
-                            if (pr < best_prim) { best_slot = slot; best_prim = pr; }
+                // LEAFW records are fetched at once (one memory round trip per LEAFW triangles);
+                // the triangle array is padded so that reading past a short leaf stays in bounds
+                for (uint32_t k0 = 0; k0 < cnt; k0 += LEAFW) {
+                    float4 ra[LEAFW], rb[LEAFW], rc[LEAFW];
+#pragma unroll
+                    for (int j = 0; j < LEAFW; ++j) {
+                        const float4* tr = p.tris + (size_t)(first + k0 + j) * 3;
+                        ra[j] = tr[0]; rb[j] = tr[1]; rc[j] = tr[2];
+                    }
+#pragma unroll
+                    for (int j = 0; j < LEAFW; ++j) {
+                        if (k0 + j < cnt) {
+                            const uint32_t slot = first + k0 + j;
+                            const float4 a = ra[j], b = rb[j], c = rc[j];
+                            const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
+                            float t;
+                            if (tri_hit(o, d, sl, v0, v1, v2, ng, t)) {
+                                if (t < tbest) {
+                                    tbest = t; best_slot = slot; best_prim = 0xFFFFFFFFu;
+                                } else if (t == tbest) {
+                                    if (best_prim == 0xFFFFFFFFu) best_prim = p.slot_prim[best_slot];
+                                    const uint32_t pr = p.slot_prim[slot];
+                                    if (pr < best_prim) { best_slot = slot; best_prim = pr; }
+                                }
+                            }
                         }
                     }
                 }
@@ -195,7 +228,6 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams p) {
             ref = s_stack[sp * kBlock + tid];
         }
     }
-done:
 
     // ---- fused write-back ----
     bool keep = best_slot != 0xFFFFFFFFu;
@@ -391,10 +423,13 @@ int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32
     for (uint64_t i = 0; i < 3 * T; ++i)
         if (tris3[i] >= V)
             return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: triangle index out of range");
-    for (uint64_t i = 0; i < 3 * V; ++i)
-        if (!(std::fabs(verts3[i]) <= 1.0e6f))
+    for (uint64_t i = 0; i < 3 * V; ++i) {
+        uint32_t u;   // bit test: immune to any finite-math assumption of the compiler
+        std::memcpy(&u, &verts3[i], 4);
+        if ((u & 0x7FFFFFFFu) > 0x49742400u /* 1e6f */)
             return fail(LRC_ERR_INVALID_ARG,
                         "lrc_scene_create: vertex coordinate is not finite or exceeds 1e6");
+    }
     LRC_HIP(hipSetDevice(ctx->device));
 
     lrc_scene* s = new (std::nothrow) lrc_scene();
@@ -482,10 +517,21 @@ static int launch_trace(lrc_scene* s, TraceParams& p, bool gen, hipStream_t st) 
     if (p.total == 0) return LRC_OK;
     const uint64_t nblk = (p.total + kBlock - 1) / kBlock;
     if (nblk > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "too many rays for one launch");
-    if (gen)
-        hipLaunchKernelGGL(trace_kernel<true>, dim3((uint32_t)nblk), dim3(kBlock), 0, st, p);
-    else
-        hipLaunchKernelGGL(trace_kernel<false>, dim3((uint32_t)nblk), dim3(kBlock), 0, st, p);
+    // stack entries needed = deepest leaf depth (one pending sibling per inner level above it)
+    const uint32_t depth = s->info.max_depth < 1 ? 1 : s->info.max_depth;
+    const size_t lds = (size_t)depth * kBlock * sizeof(int);
+    static const int leafw = [] { const char* e = std::getenv("LRC_LEAFW"); return e ? std::atoi(e) : 1; }();
+    static const int uni = [] { const char* e = std::getenv("LRC_UNIFORM"); return e ? std::atoi(e) : 1; }();
+#define LRC_LAUNCH(G, W, U) \
+    hipLaunchKernelGGL((trace_kernel<G, W, U>), dim3((uint32_t)nblk), dim3(kBlock), lds, st, p)
+#define LRC_PICK(G)                                                                  \
+    do {                                                                             \
+        if (uni) { if (leafw == 2) LRC_LAUNCH(G, 2, true); else LRC_LAUNCH(G, 1, true); }   \
+        else { if (leafw == 2) LRC_LAUNCH(G, 2, false); else LRC_LAUNCH(G, 1, false); }     \
+    } while (0)
+    if (gen) LRC_PICK(true); else LRC_PICK(false);
+#undef LRC_PICK
+#undef LRC_LAUNCH
     LRC_HIP(hipGetLastError());
     s->launches += 1;
     s->rays += p.total;

@@ -1,0 +1,23 @@
+#!/bin/bash
+# tools/pmc.sh <tag> -- rocprofv3 counter passes over a short bench.py run (GPU box only).
+# Counters are collected in their own runs (no tracing domains besides --kernel-trace), one group per pass.
+set -u
+TAG=${1:-pmc}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+i=0
+for grp in \
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" \
+  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS" \
+  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum" \
+  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" \
+  "FETCH_SIZE" \
+  "WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" ; do
+  i=$((i+1))
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+done
+python3 $R/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt

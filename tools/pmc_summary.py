@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Average each PMC counter per dispatch of every kernel whose name matches (default: trace_kernel)."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+root = sys.argv[1]
+pat = sys.argv[2] if len(sys.argv) > 2 else "trace_kernel"
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True)):
+    per = collections.defaultdict(float)
+    for r in csv.DictReader(open(f)):
+        if pat not in r["Kernel_Name"]:
+            continue
+        per[(r["Dispatch_Id"], r["Counter_Name"], r["Kernel_Name"][:60])] += float(r["Counter_Value"])
+    for (d, c, k), v in per.items():
+        acc[k][c].append(v)
+for k, cs in acc.items():
+    print(k)
+    for c, vs in sorted(cs.items()):
+        print(f"  {c:34s} n={len(vs):3d} mean={sum(vs)/len(vs):.6g}")

@@ -49,7 +49,11 @@ int fail(int code, const std::string& msg) {
         }                                                                                  \
     } while (0)
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 256;          // compaction kernels
+#ifndef LRC_TRACE_BLOCK
+#define LRC_TRACE_BLOCK 64
+#endif
+constexpr int kTBlock = LRC_TRACE_BLOCK;   // trace kernel workgroup (rays per tile)
 constexpr int kStack = LRC_MAX_BVH_DEPTH;
 
 }  // namespace
@@ -109,11 +113,11 @@ __device__ __forceinline__ F4 ld_uniform(const float4* gp) {
     return F4{c[0], c[1], c[2], c[3]};
 }
 
-template <bool GEN, int LEAFW, bool UNI>
-__global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams p) {
-    extern __shared__ int s_stack[];   // [stack depth][kBlock]: one column per lane, conflict free
+template <bool GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false>
+__global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
+    extern __shared__ int s_stack[];   // [stack depth][kTBlock]: one column per lane, conflict free
     const uint32_t tid = threadIdx.x;
-    const uint64_t gid = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * kBlock + tid;
+    const uint64_t gid = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * kTBlock + tid;
     if (gid >= p.total) return;
 
     // ---- the ray ----
@@ -145,12 +149,14 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams p) {
     uint32_t best_slot = 0xFFFFFFFFu;
     uint32_t best_prim = 0xFFFFFFFFu;   // loaded lazily, only to break exact ties
 
+    float st_nodes = 0.f, st_tris = 0.f, st_uni = 0.f, st_dead = 0.f;   // STATS build only (tools/trav_stats.py)
     if (p.num_nodes) {
         int sp = 0;
         int ref = 0;   // root
         // one inner-node step: test both child boxes, descend into the nearer hit child, push the other;
         // nothing hit -> pop, or (stack empty) continue with the empty leaf so that the outer loop ends
         auto step = [&](const F4 q0, const F4 q1, const F4 q2, const F4 q3) {
+            if (STATS) st_nodes += 1.0f;
             float n0, f0, n1, f1;
             slab_interval(sl, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, n0, f0);
             slab_interval(sl, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, n1, f1);
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams p) {
             const int r0 = __float_as_int(q3.x), r1 = __float_as_int(q3.y);
             if (h0 & h1) {
                 const bool first0 = n0 <= n1;
-                s_stack[sp * kBlock + tid] = first0 ? r1 : r0;
+                s_stack[sp * kTBlock + tid] = first0 ? r1 : r0;
                 ++sp;
                 ref = first0 ? r0 : r1;
             } else if (h0) {
@@ -167,14 +173,51 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams p) {
             } else if (h1) {
                 ref = r1;
             } else if (sp == 0) {
+                if (STATS) st_dead += 1.0f;
                 ref = ~0;   // empty leaf
             } else {
+                if (STATS) st_dead += 1.0f;
                 --sp;
-                ref = s_stack[sp * kBlock + tid];
+                ref = s_stack[sp * kTBlock + tid];
+            }
+        };
+        // one leaf: test its 1..4 triangles, keep the lexicographically smallest (t, triangle row)
+        auto leaf = [&](const int lref) {
+            const uint32_t enc = (uint32_t)(~lref);
+            const uint32_t first = enc >> 3, cnt = enc & 7u;
+            // LEAFW records are fetched at once (one memory round trip per LEAFW triangles);
+            // the triangle array is padded so that reading past a short leaf stays in bounds
+            for (uint32_t k0 = 0; k0 < cnt; k0 += LEAFW) {
+                float4 ra[LEAFW], rb[LEAFW], rc[LEAFW];
+#pragma unroll
+                for (int j = 0; j < LEAFW; ++j) {
+                    const float4* tr = p.tris + (size_t)(first + k0 + j) * 3;
+                    ra[j] = tr[0]; rb[j] = tr[1]; rc[j] = tr[2];
+                }
+#pragma unroll
+                for (int j = 0; j < LEAFW; ++j) {
+                    if (k0 + j < cnt) {
+                        if (STATS) st_tris += 1.0f;
+                        const uint32_t slot = first + k0 + j;
+                        const float4 a = ra[j], b = rb[j], c = rc[j];
+                        const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
+                        float t;
+                        if (tri_hit(o, d, sl, v0, v1, v2, ng, t)) {
+                            if (t < tbest) {
+                                tbest = t; best_slot = slot; best_prim = 0xFFFFFFFFu;
+                            } else if (t == tbest) {
+                                if (best_prim == 0xFFFFFFFFu) best_prim = p.slot_prim[best_slot];
+                                const uint32_t pr = p.slot_prim[slot];
+                                if (pr < best_prim) { best_slot = slot; best_prim = pr; }
+                            }
+                        }
+                    }
+                }
             }
         };
         while (true) {
             // descend inner nodes
+            int pending = ~0;   // SPEC: one postponed leaf (empty = ~0)
             while (ref >= 0) {
                 if (UNI) {
                     // Neighbouring rays walk the top of the tree in lock step.  When every active lane
@@ -182,50 +225,32 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams p) {
                     // SGPRs (s_load) instead of 64 identical 64-byte vector loads through the L1.
                     const int uref = __builtin_amdgcn_readfirstlane(ref);
                     if (__builtin_amdgcn_ballot_w64(ref != uref) == 0ull) {
+                        if (STATS) st_uni += 1.0f;
                         const float4* n = p.nodes + (size_t)uref * 4;
                         step(ld_uniform(n), ld_uniform(n + 1), ld_uniform(n + 2), ld_uniform(n + 3));
-                        continue;
+                    } else {
+                        const F4* n = (const F4*)(p.nodes + (size_t)ref * 4);
+                        step(n[0], n[1], n[2], n[3]);
                     }
+                } else {
+                    const F4* n = (const F4*)(p.nodes + (size_t)ref * 4);
+                    step(n[0], n[1], n[2], n[3]);
                 }
-                const F4* n = (const F4*)(p.nodes + (size_t)ref * 4);
-                step(n[0], n[1], n[2], n[3]);
-            }
-            // leaf
-            {
-                const uint32_t enc = (uint32_t)(~ref);
-                const uint32_t first = enc >> 3, cnt = enc & 7u;
-                // LEAFW records are fetched at once (one memory round trip per LEAFW triangles);
-                // the triangle array is padded so that reading past a short leaf stays in bounds
-                for (uint32_t k0 = 0; k0 < cnt; k0 += LEAFW) {
-                    float4 ra[LEAFW], rb[LEAFW], rc[LEAFW];
-#pragma unroll
-                    for (int j = 0; j < LEAFW; ++j) {
-                        const float4* tr = p.tris + (size_t)(first + k0 + j) * 3;
-                        ra[j] = tr[0]; rb[j] = tr[1]; rc[j] = tr[2];
-                    }
-#pragma unroll
-                    for (int j = 0; j < LEAFW; ++j) {
-                        if (k0 + j < cnt) {
-                            const uint32_t slot = first + k0 + j;
-                            const float4 a = ra[j], b = rb[j], c = rc[j];
-                            const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
-                            float t;
-                            if (tri_hit(o, d, sl, v0, v1, v2, ng, t)) {
-                                if (t < tbest) {
-                                    tbest = t; best_slot = slot; best_prim = 0xFFFFFFFFu;
-                                } else if (t == tbest) {
-                                    if (best_prim == 0xFFFFFFFFu) best_prim = p.slot_prim[best_slot];
-                                    const uint32_t pr = p.slot_prim[slot];
-                                    if (pr < best_prim) { best_slot = slot; best_prim = pr; }
-                                }
-                            }
-                        }
+                if (SPEC) {
+                    // speculative traversal: park the first leaf and keep descending from the stack, so
+                    // that this lane stays busy while its neighbours are still in inner nodes
+                    if ((ref < 0) & (ref != ~0) & (pending == ~0) & (sp > 0)) {
+                        pending = ref;
+                        --sp;
+                        ref = s_stack[sp * kTBlock + tid];
                     }
                 }
             }
+            if (SPEC) leaf(pending);
+            leaf(ref);
             if (sp == 0) break;
             --sp;
-            ref = s_stack[sp * kBlock + tid];
+            ref = s_stack[sp * kTBlock + tid];
         }
     }
 
@@ -261,6 +286,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams p) {
     }
     if (p.out.t) p.out.t[gid] = t_out;
     if (p.out.prim) p.out.prim[gid] = prim;
+    if (STATS) { nx = st_nodes; ny = st_tris; nz = st_uni + st_dead / 1024.0f; }   // nz = uniform + dead/1024
     if (p.out.normal3) { float* q = p.out.normal3 + gid * 3; q[0] = nx; q[1] = ny; q[2] = nz; }
     if (p.out.point3) { float* q = p.out.point3 + gid * 3; q[0] = px; q[1] = py; q[2] = pz; }
     if (p.out.sem) p.out.sem[gid] = (uint16_t)(label & 0xFFFFu);
@@ -515,21 +541,27 @@ static int launch_trace(lrc_scene* s, TraceParams& p, bool gen, hipStream_t st) 
     p.slot_label = s->d_slot_label;
     p.num_nodes = (uint32_t)s->info.num_nodes;
     if (p.total == 0) return LRC_OK;
-    const uint64_t nblk = (p.total + kBlock - 1) / kBlock;
+    const uint64_t nblk = (p.total + kTBlock - 1) / kTBlock;
     if (nblk > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "too many rays for one launch");
     // stack entries needed = deepest leaf depth (one pending sibling per inner level above it)
     const uint32_t depth = s->info.max_depth < 1 ? 1 : s->info.max_depth;
-    const size_t lds = (size_t)depth * kBlock * sizeof(int);
+    const size_t lds = (size_t)depth * kTBlock * sizeof(int);
     static const int leafw = [] { const char* e = std::getenv("LRC_LEAFW"); return e ? std::atoi(e) : 1; }();
     static const int uni = [] { const char* e = std::getenv("LRC_UNIFORM"); return e ? std::atoi(e) : 1; }();
-#define LRC_LAUNCH(G, W, U) \
-    hipLaunchKernelGGL((trace_kernel<G, W, U>), dim3((uint32_t)nblk), dim3(kBlock), lds, st, p)
+    static const int spec = [] { const char* e = std::getenv("LRC_SPEC"); return e ? std::atoi(e) : 0; }();
+#define LRC_LAUNCH(G, W, U, S) \
+    hipLaunchKernelGGL((trace_kernel<G, W, U, S>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p)
 #define LRC_PICK(G)                                                                  \
     do {                                                                             \
-        if (uni) { if (leafw == 2) LRC_LAUNCH(G, 2, true); else LRC_LAUNCH(G, 1, true); }   \
-        else { if (leafw == 2) LRC_LAUNCH(G, 2, false); else LRC_LAUNCH(G, 1, false); }     \
+        if (spec) { if (leafw == 2) LRC_LAUNCH(G, 2, true, true); else LRC_LAUNCH(G, 1, true, true); }        \
+        else if (uni) { if (leafw == 2) LRC_LAUNCH(G, 2, true, false); else LRC_LAUNCH(G, 1, true, false); }  \
+        else { if (leafw == 2) LRC_LAUNCH(G, 2, false, false); else LRC_LAUNCH(G, 1, false, false); }         \
     } while (0)
-    if (gen) LRC_PICK(true); else LRC_PICK(false);
+    static const int stats = [] { const char* e = std::getenv("LRC_STATS"); return e ? std::atoi(e) : 0; }();
+    if (stats) {   // diagnostic build: per-ray traversal counters replace the normals (tools/trav_stats.py)
+        if (gen) hipLaunchKernelGGL((trace_kernel<true, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
+        else hipLaunchKernelGGL((trace_kernel<false, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
+    } else if (gen) LRC_PICK(true); else LRC_PICK(false);
 #undef LRC_PICK
 #undef LRC_LAUNCH
     LRC_HIP(hipGetLastError());

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "liblidarcast.so")
+LIB_PATH = os.environ.get("LRC_LIB") or os.path.join(_PKG_ROOT, "liblidarcast.so")   # LRC_LIB: A/B builds
 
 LRC_OK = 0
 LRC_ERR_INVALID_ARG = -1

@@ -40,6 +40,22 @@ def bytes_per_ray(T, in_kernel_raygen=True):
     return (0 if in_kernel_raygen else 24) + 36 + 64 * levels + 144
 
 
+def measured_traffic(kernel_prefix, rays_per_launch):
+    """HBM-side bytes per launch of the trace kernel from the committed rocprofv3 PMC summary
+    (profiles/traffic_latest.json, produced by tools/pmc.sh on this same command): FETCH_SIZE doubled per the
+    gfx950 note of MI355X_MICROARCH.md (128-B requests tallied at 64 B) + WRITE_SIZE, KB -> bytes.
+    None when no profile of this kernel/workload is committed."""
+    path = os.path.join(REPO, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("rays_per_launch") != rays_per_launch or not t["kernel"].startswith(kernel_prefix):
+            return None
+        return (2.0 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def c3_sensor():
     import dataclasses
     from lidar import Indoor8LineLidarIntrinsics
@@ -55,42 +71,47 @@ def c3_poses(rank, world):
     return poses_from_waypoints(wps[rank * POSES_PER_GPU:(rank + 1) * POSES_PER_GPU])
 
 
-def cpu_baseline(mesh, sensor, poses, budget_s=20.0):
+def host_threads():
+    """Threads for the CPU leg: the cores this process may run on, capped at 32 (a one-GPU box share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(mesh, sensor, poses, budget_s=18.0):
     """Reference-faithful CPU figure: per pose, host ray generation + BVH rebuild (the reference rebuilds
-    the Embree scene on every call, raycast_engine_cpu.py:46-47) + cast + numpy post-processing, on all
-    host cores, for as many poses as fit the budget.  Also the build-once variant."""
+    the Embree scene on every call, raycast_engine_cpu.py:46-47) + cast + numpy post-processing, for as
+    many poses of the workload as fit the time budget.  Also the build-once variant."""
     from lidar import create_lidar
     from oracle import np_oracle
     from oracle.c_oracle import OracleMesh
-    cores = os.cpu_count() or 1
+    threads = host_threads()
     n_per = sensor.vertical_res * sensor.horizontal_res
     t_start = time.perf_counter()
     done, t_faithful = 0, 0.0
-    for p in range(len(poses)):
+    while done < len(poses) and time.perf_counter() - t_start < budget_s * 0.65:
         t0 = time.perf_counter()
         om = OracleMesh(mesh.vertices, mesh.triangles).build()       # per-pose scene rebuild
-        lidar = create_lidar(sensor, poses[p])
-        np_oracle.lidar_intersect_mesh(om, lidar, threads=cores)
+        np_oracle.lidar_intersect_mesh(om, create_lidar(sensor, poses[done]), threads=threads)
         om.free()
         t_faithful += time.perf_counter() - t0
         done += 1
-        if time.perf_counter() - t_start > budget_s * 0.6 or done >= 8:
-            break
     om = OracleMesh(mesh.vertices, mesh.triangles).build()
     t0 = time.perf_counter()
     done_once = 0
-    for p in range(len(poses)):
-        np_oracle.lidar_intersect_mesh(om, create_lidar(sensor, poses[p]), threads=cores)
+    while done_once < len(poses) and time.perf_counter() - t0 < budget_s * 0.3:
+        np_oracle.lidar_intersect_mesh(om, create_lidar(sensor, poses[done_once]), threads=threads)
         done_once += 1
-        if time.perf_counter() - t0 > budget_s * 0.3 or done_once >= 16:
-            break
     t_once = time.perf_counter() - t0
     return {
-        "value": done * n_per / t_faithful, "unit": "rays/s", "cores": cores, "kind": "port",
-        "sample": f"{done} of {len(poses)} poses x {n_per} rays of the C3 workload, BVH rebuilt per pose "
-                  f"as the reference does; oracle/lrc_oracle.c (C, pthreads) + numpy post-processing",
+        "value": done * n_per / t_faithful, "unit": "rays/s", "cores": threads, "kind": "port",
+        "sample": f"{done} of {len(poses)} poses x {n_per} rays of the C3 workload ({t_faithful:.1f} s of CPU work), "
+                  f"scene (BVH) rebuilt per pose as the reference does; oracle/lrc_oracle.c (C, pthreads) + "
+                  f"numpy ray generation and post-processing",
         "build_once_value": done_once * n_per / t_once,
-        "build_once_sample": f"{done_once} poses, BVH built once",
+        "build_once_sample": f"{done_once} poses in {t_once:.1f} s, BVH built once",
     }
 
 
@@ -190,6 +211,7 @@ def main():
     value = total_rays / elapsed
     bpr = bytes_per_ray(info["num_triangles"])
     achieved = n * bpr / (kernel_ms * 1e-3) / 1e9
+    traffic = measured_traffic("void (anonymous namespace)::trace_kernel<true", n) if args.scene == SCENE else None
 
     if rank == 0:
         res = {
@@ -209,9 +231,14 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "trace_kernel<true>", "kernel_ms": kernel_ms, "bytes_per_ray": bpr,
-                "rays_per_launch": n,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "trace_kernel<GEN=true>", "kernel_ms": kernel_ms, "bytes_per_ray": bpr,
+                "rays_per_launch": n, "algorithmic_bytes_per_launch": n * bpr,
+                "note": "achieved = algorithmic bytes (SURVEY 8(d): 36 B record + 64 B x ceil(log2(T/4)) descent + "
+                        "144 B leaf, per ray) / kernel time; neighbouring rays re-use nodes from L1/L2/Infinity "
+                        "Cache, so it can exceed the HBM peak. traffic = measured HBM-side bytes per launch "
+                        "(2 x FETCH_SIZE + WRITE_SIZE from profiles/traffic_latest.json)"
+                        + ("" if traffic is None else f" = {traffic / (kernel_ms * 1e-3) / 1e9:.0f} GB/s"),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

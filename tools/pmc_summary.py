@@ -21,3 +21,14 @@ for k, cs in acc.items():
     print(k)
     for c, vs in sorted(cs.items()):
         print(f"  {c:34s} n={len(vs):3d} mean={sum(vs)/len(vs):.6g}")
+
+# traffic summary for bench.py (profiles/traffic_latest.json)
+import json
+for k, cs in acc.items():
+    if "trace_kernel<true" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        mean = lambda v: sum(v) / len(v)
+        out = {"kernel": k, "FETCH_SIZE_KB": mean(cs["FETCH_SIZE"]), "WRITE_SIZE_KB": mean(cs["WRITE_SIZE"]),
+               "rays_per_launch": 4194304, "command": "bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+               "counters": {c: mean(v) for c, v in sorted(cs.items())}}
+        with open(os.path.join(root, "traffic.json"), "w") as f:
+            json.dump(out, f, indent=1)

@@ -129,7 +129,6 @@ def main():
     import lidarcast
     from lidarcast import synth
     from lidarcast._capi import LrcCompactIO
-    from lidarcast.distributed import gather_cloud
     from lidar import IndoorLidar
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,17 +156,21 @@ def main():
     n = P * N
     d_poses = torch.from_numpy(poses.reshape(P, 16)).to(dev)
     d_dirs = torch.from_numpy(dirs).to(dev)
-    hits = lidarcast.DeviceHits(n, dev, want=("t", "prim", "normal3", "point3", "sem", "ins"))
-    label = torch.empty(0)
-    out_pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    out_sem = torch.empty(n, dtype=torch.int16, device=dev)
-    out_ins = torch.empty(n, dtype=torch.int16, device=dev)
-    counts = torch.zeros(P, dtype=torch.int64, device=dev)
+    hits = lidarcast.DeviceHits(n, dev, want=("t", "prim", "normal3", "point3", "sem", "ins", "tile_count"))
+    # scene cloud: compacted 16-byte rows (x, y, z, sem|ins<<16) in np.vstack order + per-pose counts
+    if world > 1:
+        from lidarcast.distributed import CloudGather
+        gather = CloudGather(n, P, dist, dev)
+        cloud, counts = gather.slab, gather.counts
+    else:
+        gather = None
+        cloud = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        counts = torch.zeros(P, dtype=torch.int64, device=dev)
     io = LrcCompactIO()
     io.t, io.point3 = hits["t"].data_ptr(), hits["point3"].data_ptr()
     io.sem, io.ins = hits["sem"].data_ptr(), hits["ins"].data_ptr()
-    io.counts, io.out_point3 = counts.data_ptr(), out_pts.data_ptr()
-    io.out_sem, io.out_ins = out_sem.data_ptr(), out_ins.data_ptr()
+    io.tile_count = hits["tile_count"].data_ptr()
+    io.counts, io.out_xyzl = counts.data_ptr(), cloud.data_ptr()
     stream = torch.cuda.current_stream().cuda_stream
 
     k_events = []
@@ -181,11 +184,8 @@ def main():
             e1.record()
             k_events.append((e0, e1))
         ctx.compact_dev(P, N, io, stream)
-        if world > 1:
-            k = int(counts.sum().item())
-            lab = (out_sem[:k].to(torch.int32) & 0xFFFF) | (out_ins[:k].to(torch.int32) << 16)
-            return gather_cloud(out_pts[:k], lab, counts, n, dist)
-        return None
+        if gather is not None:
+            gather.gather()          # one RCCL all-gather of the rows (+ the tiny one of the counts)
 
     def barrier():
         if world > 1:
@@ -227,7 +227,8 @@ def main():
                 "bvh": {"nodes": info["num_nodes"], "depth": info["max_depth"],
                         "build_ms": round(info["build_ms"], 1), "device_MB": round(info["device_bytes"] / 1e6, 1)},
                 "step": "in-kernel ray generation + BVH traversal + hit write-back (36 B/ray) + stable "
-                        "compaction" + (" + RCCL all-gather of the clouds" if world > 1 else ""),
+                        "compaction into the scene cloud (16 B/hit)"
+                        + (" + one RCCL all-gather of the clouds" if world > 1 else ""),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

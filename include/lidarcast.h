@@ -59,6 +59,9 @@ typedef struct lrc_hits {
     uint16_t* ins;           /* (n)    instance label of the hit triangle; 0 on miss                 */
     double*   incident_deg;  /* (n)    degrees(arccos(|((p-c)/|p-c|)_z|)) in float64
                                        (raycast_engine_cpu.py:100-107); 0 on miss                    */
+    uint32_t* tile_count;    /* (ceil(n/64)) DEVICE entry points only: number of kept entries in each
+                                       aligned run of 64 outputs; lets lrc_compact_dev skip its counting
+                                       pass (lrc_compact_io.tile_count).  Ignored by the host entry points */
 } lrc_hits;
 
 typedef struct lrc_scene_info {
@@ -107,8 +110,8 @@ int lrc_scene_destroy(lrc_scene* scene);
 int lrc_scene_get_info(const lrc_scene* scene, lrc_scene_info* out_info);
 
 /* Copy the BVH back to host arrays (tests check its invariants).  Any pointer may be NULL.
- *   nodes64 : num_nodes * 16 floats  (lo0 xyz, hi0 xyz, lo1 xyz, hi1 xyz, ref0, ref1, 0, 0; refs are
- *             int32 bit patterns: >=0 inner node index, <0 leaf: ~ref = first_slot*8 + (count-1))
+ *   nodes16 : num_nodes * 16 floats  (lo0 xyz, hi0 xyz, lo1 xyz, hi1 xyz, ref0, ref1, 0, 0; refs are
+ *             int32 bit patterns: >=0 inner node index, <0 leaf: ~ref = first_slot*8 + count)
  *   slot_prim: num_slots uint32 (triangle row index stored in each leaf slot) */
 int lrc_scene_export_bvh(const lrc_scene* scene, float* nodes16, uint32_t* slot_prim);
 
@@ -147,7 +150,7 @@ int lrc_scan_poses_dev(lrc_scene* scene, const double* d_poses16, uint64_t num_p
  * the kept entries of all segments are packed back to back, which is the order of
  * np.vstack over frames (containers/s3dis_sim_scene.py:326,362).  Optional gathers (NULL = skip):
  * point3 -> out_point3 (K,3), sem/ins -> out_sem/out_ins (K), incident -> out_incident (K),
- * out_index (K) = index of the kept entry inside its segment.
+ * out_index (K) = index of the kept entry inside its segment, out_xyzl (K,4) = point + packed labels.
  * Host variant returns the total K in *out_total. */
 typedef struct lrc_compact_io {
     const float*    t;
@@ -155,12 +158,16 @@ typedef struct lrc_compact_io {
     const uint16_t* sem;
     const uint16_t* ins;
     const double*   incident_deg;
+    const uint32_t* tile_count;    /* optional, device entry point only: lrc_hits.tile_count of the scan
+                                      that produced t (used when seg_len % 64 == 0)                   */
     uint64_t*       counts;        /* (num_segments)                                  */
     float*          out_point3;
     uint16_t*       out_sem;
     uint16_t*       out_ins;
     double*         out_incident_deg;
     uint32_t*       out_index;
+    float*          out_xyzl;      /* (K,4) packed rows x, y, z, label bits (sem | ins<<16): the 16-byte
+                                      row the multi-GPU all-gather moves                              */
 } lrc_compact_io;
 
 int lrc_compact(lrc_ctx* ctx, uint64_t num_segments, uint64_t seg_len,

@@ -60,9 +60,12 @@ constexpr int kStack = LRC_MAX_BVH_DEPTH;
 
 struct lrc_ctx {
     int device = 0;
-    // compaction scratch (grown on demand, reused)
-    uint64_t* d_block_off = nullptr;
-    uint64_t block_off_cap = 0;
+    // compaction scratch (grown on demand, reused): per-tile counts and exclusive offsets
+    uint32_t* d_tile_off = nullptr;     // offset of a tile inside its super tile (1024 tiles)
+    uint32_t* d_tile_cnt = nullptr;
+    uint32_t* d_super_total = nullptr;  // kept entries per super tile
+    uint64_t* d_super_base = nullptr;   // exclusive prefix of d_super_total (+ grand total)
+    uint64_t tile_cap = 0;
 };
 
 struct lrc_scene {
@@ -284,6 +287,10 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
             px = py = pz = 0.f;
         }
     }
+    if (p.out.tile_count) {   // kept rays of this wave's 64 consecutive outputs (feeds lrc_compact_dev)
+        const unsigned long long m = __ballot(keep);
+        if ((tid & 63u) == 0) p.out.tile_count[gid >> 6] = (uint32_t)__popcll(m);
+    }
     if (p.out.t) p.out.t[gid] = t_out;
     if (p.out.prim) p.out.prim[gid] = prim;
     if (STATS) { nx = st_nodes; ny = st_tris; nz = st_uni + st_dead / 1024.0f; }   // nz = uniform + dead/1024
@@ -295,83 +302,109 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
 }
 
 // ---- compaction -------------------------------------------------------------------------------
-// block b <-> (segment b / bps, chunk b % bps); each block covers kBlock consecutive entries.
+// tile = 64 consecutive entries of one segment = one wave; tile index = seg * tps + chunk.
 
 __global__ __launch_bounds__(kBlock) void compact_count_kernel(const float* t, uint64_t seg_len,
-                                                               uint64_t bps, uint64_t* block_cnt) {
-    __shared__ uint32_t s_w[kBlock / 64];
-    const uint64_t b = blockIdx.x;
-    const uint64_t seg = b / bps, chunk = b - seg * bps;
-    const uint64_t i = chunk * kBlock + threadIdx.x;
+                                                               uint64_t tps, uint64_t ntiles,
+                                                               uint32_t* tile_cnt) {
+    const uint64_t tile = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const uint64_t seg = tile / tps, chunk = tile - seg * tps;
+    const uint64_t i = chunk * 64 + (threadIdx.x & 63u);
     bool keep = false;
     if (i < seg_len) keep = t[seg * seg_len + i] < __builtin_inff();
     const unsigned long long m = __ballot(keep);
-    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t c = 0;
-        for (int w = 0; w < kBlock / 64; ++w) c += s_w[w];
-        block_cnt[b] = c;
-    }
+    if ((threadIdx.x & 63u) == 0) tile_cnt[tile] = (uint32_t)__popcll(m);
 }
 
-// single workgroup: exclusive scan of nblocks counts in place, total at [nblocks], then segment counts
-__global__ __launch_bounds__(1024) void compact_scan_kernel(uint64_t* block_off, uint64_t nblocks,
-                                                            uint64_t bps, uint64_t nseg,
-                                                            uint64_t* seg_counts) {
+// Pass A: every workgroup scans its own run of 1024 tile counts (a "super tile" = 65536 entries):
+// tile_off[tile] = exclusive offset inside the super tile, super_total[b] = its sum.
+__global__ __launch_bounds__(1024) void compact_scan_kernel(const uint32_t* tile_cnt, uint32_t* tile_off,
+                                                            uint64_t ntiles, uint32_t* super_total) {
+    __shared__ uint32_t s_wave[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint64_t tile = (uint64_t)blockIdx.x * 1024 + tid;
+    const uint32_t c = tile < ntiles ? tile_cnt[tile] : 0u;
+    uint32_t incl = c;                       // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+    }
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < w; ++k) base += s_wave[k];
+    if (tile < ntiles) tile_off[tile] = base + incl - c;
+    if (tid == 1023) super_total[blockIdx.x] = base + incl;
+}
+
+// Pass A2: one workgroup turns the super-tile totals into exclusive bases (base[nsuper] = grand total).
+__global__ __launch_bounds__(1024) void compact_base_kernel(const uint32_t* super_total, uint64_t* super_base,
+                                                            uint64_t nsuper) {
     __shared__ uint64_t s_part[1024];
     __shared__ uint64_t s_carry;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (uint64_t base = 0; base < nblocks; base += 1024) {
+    for (uint64_t base = 0; base < nsuper; base += 1024) {
         const uint64_t i = base + tid;
-        const uint64_t v = i < nblocks ? block_off[i] : 0;
+        const uint64_t v = i < nsuper ? super_total[i] : 0;
         s_part[tid] = v;
         __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
-            uint64_t add = tid >= off ? s_part[tid - off] : 0;
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            const uint64_t add = tid >= off ? s_part[tid - off] : 0;
             __syncthreads();
             s_part[tid] += add;
             __syncthreads();
         }
         const uint64_t carry = s_carry;
-        if (i < nblocks) block_off[i] = carry + s_part[tid] - v;
+        if (i < nsuper) super_base[i] = carry + s_part[tid] - v;
         __syncthreads();
         if (tid == 1023) s_carry = carry + s_part[1023];
         __syncthreads();
     }
-    if (tid == 0) block_off[nblocks] = s_carry;
-    __threadfence_block();
-    __syncthreads();
-    if (seg_counts) {
-        for (uint64_t s = tid; s < nseg; s += 1024)
-            seg_counts[s] = block_off[(s + 1) * bps] - block_off[s * bps];
-    }
+    if (tid == 0) super_base[nsuper] = s_carry;
 }
 
+// Pass B: scatter the kept entries; the first workgroups also write the per-segment counts.
 __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const lrc_compact_io io,
-                                                                 uint64_t seg_len, uint64_t bps,
-                                                                 const uint64_t* block_off) {
-    __shared__ uint32_t s_w[kBlock / 64];
-    const uint64_t b = blockIdx.x;
-    const uint64_t seg = b / bps, chunk = b - seg * bps;
-    const uint64_t i = chunk * kBlock + threadIdx.x;
+                                                                 uint64_t seg_len, uint64_t tps,
+                                                                 uint64_t ntiles, uint64_t nseg,
+                                                                 const uint32_t* tile_off,
+                                                                 const uint64_t* super_base) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (io.counts) {
+        // one thread per segment: count = global offset of its end tile - global offset of its first tile
+        const uint64_t sg = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (sg < nseg) {
+            const uint64_t nsuper = (ntiles + 1023) / 1024;
+            const uint64_t g0 = sg * tps, g1 = g0 + tps;
+            const uint64_t o0 = g0 >= ntiles ? super_base[nsuper] : super_base[g0 >> 10] + tile_off[g0];
+            const uint64_t o1 = g1 >= ntiles ? super_base[nsuper] : super_base[g1 >> 10] + tile_off[g1];
+            io.counts[sg] = o1 - o0;
+        }
+    }
+    const uint64_t tile = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const uint64_t seg = tile / tps, chunk = tile - seg * tps;
+    const uint64_t i = chunk * 64 + lane;
     const uint64_t src = seg * seg_len + i;
     bool keep = false;
     if (i < seg_len) keep = io.t[src] < __builtin_inff();
     const unsigned long long m = __ballot(keep);
-    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    if (lane == 0) s_w[w] = (uint32_t)__popcll(m);
-    __syncthreads();
     if (!keep) return;
-    uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    for (uint32_t k = 0; k < w; ++k) before += s_w[k];
-    const uint64_t dst = block_off[b] + before;
+    const uint64_t tbase = super_base[tile >> 10] + tile_off[tile];
+    const uint64_t dst = tbase + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (io.out_xyzl) {
+        const float* sp = io.point3 + src * 3;
+        const uint32_t lab = (io.sem ? (uint32_t)io.sem[src] : 0u) | ((io.ins ? (uint32_t)io.ins[src] : 0u) << 16);
+        ((float4*)io.out_xyzl)[dst] = make_float4(sp[0], sp[1], sp[2], __uint_as_float(lab));
+    }
     if (io.out_point3) {
-        const float* s = io.point3 + src * 3;
+        const float* sp = io.point3 + src * 3;
         float* q = io.out_point3 + dst * 3;
-        q[0] = s[0]; q[1] = s[1]; q[2] = s[2];
+        q[0] = sp[0]; q[1] = sp[1]; q[2] = sp[2];
     }
     if (io.out_sem) io.out_sem[dst] = io.sem[src];
     if (io.out_ins) io.out_ins[dst] = io.ins[src];
@@ -414,7 +447,10 @@ int lrc_ctx_create(int device, lrc_ctx** out_ctx) {
 int lrc_ctx_destroy(lrc_ctx* ctx) {
     if (!ctx) return LRC_OK;
     (void)hipSetDevice(ctx->device);
-    if (ctx->d_block_off) (void)hipFree(ctx->d_block_off);
+    if (ctx->d_tile_off) (void)hipFree(ctx->d_tile_off);
+    if (ctx->d_tile_cnt) (void)hipFree(ctx->d_tile_cnt);
+    if (ctx->d_super_total) (void)hipFree(ctx->d_super_total);
+    if (ctx->d_super_base) (void)hipFree(ctx->d_super_base);
     delete ctx;
     return LRC_OK;
 }
@@ -682,26 +718,44 @@ int lrc_compact_dev(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_com
     if (!ctx || !io) return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: NULL argument");
     if (nseg == 0 || seg_len == 0) return LRC_OK;
     if (!io->t) return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: t is NULL");
-    if ((io->out_point3 && !io->point3) || (io->out_sem && !io->sem) || (io->out_ins && !io->ins) ||
-        (io->out_incident_deg && !io->incident_deg))
+    if (((io->out_point3 || io->out_xyzl) && !io->point3) || (io->out_sem && !io->sem) ||
+        (io->out_ins && !io->ins) || (io->out_incident_deg && !io->incident_deg))
         return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: an output is requested without its input");
     LRC_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    const uint64_t bps = (seg_len + kBlock - 1) / kBlock;
-    const uint64_t nblocks = nseg * bps;
+    const uint64_t tps = (seg_len + 63) / 64;
+    const uint64_t ntiles = nseg * tps;
+    const uint64_t nblocks = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
     if (nblocks > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: too many entries");
-    if (ctx->block_off_cap < nblocks + 1) {
-        if (ctx->d_block_off) { (void)hipFree(ctx->d_block_off); ctx->d_block_off = nullptr; }
-        ctx->block_off_cap = 0;
-        LRC_HIP(hipMalloc((void**)&ctx->d_block_off, (nblocks + 1) * 8));
-        ctx->block_off_cap = nblocks + 1;
+    if (ctx->tile_cap < ntiles + 1) {
+        if (ctx->d_tile_off) { (void)hipFree(ctx->d_tile_off); ctx->d_tile_off = nullptr; }
+        if (ctx->d_tile_cnt) { (void)hipFree(ctx->d_tile_cnt); ctx->d_tile_cnt = nullptr; }
+        if (ctx->d_super_total) { (void)hipFree(ctx->d_super_total); ctx->d_super_total = nullptr; }
+        if (ctx->d_super_base) { (void)hipFree(ctx->d_super_base); ctx->d_super_base = nullptr; }
+        ctx->tile_cap = 0;
+        LRC_HIP(hipMalloc((void**)&ctx->d_tile_off, (ntiles + 1) * 4));
+        LRC_HIP(hipMalloc((void**)&ctx->d_tile_cnt, (ntiles + 1) * 4));
+        LRC_HIP(hipMalloc((void**)&ctx->d_super_total, ((ntiles + 1023) / 1024 + 1) * 4));
+        LRC_HIP(hipMalloc((void**)&ctx->d_super_base, ((ntiles + 1023) / 1024 + 1) * 8));
+        ctx->tile_cap = ntiles + 1;
     }
-    hipLaunchKernelGGL(compact_count_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, io->t,
-                       seg_len, bps, ctx->d_block_off);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, ctx->d_block_off, nblocks, bps,
-                       nseg, io->counts);
-    hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, *io,
-                       seg_len, bps, (const uint64_t*)ctx->d_block_off);
+    // the trace kernel can hand over its per-wave keep counts (lrc_hits.tile_count) when tiles line up
+    const uint32_t* cnt = (io->tile_count && seg_len % 64 == 0) ? io->tile_count : nullptr;
+    if (!cnt) {
+        hipLaunchKernelGGL(compact_count_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, io->t, seg_len,
+                           tps, ntiles, ctx->d_tile_cnt);
+        cnt = ctx->d_tile_cnt;
+    }
+    const uint64_t nsuper = (ntiles + 1023) / 1024;
+    hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(1024), 0, st, cnt, ctx->d_tile_off,
+                       ntiles, ctx->d_super_total);
+    hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)ctx->d_super_total,
+                       ctx->d_super_base, nsuper);
+    // the scatter grid must also cover the threads that write the per-segment counts (one per segment)
+    const uint64_t need = io->counts ? (nseg + kBlock - 1) / kBlock : 0;
+    const uint64_t grid = nblocks > need ? nblocks : need;
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, st, *io, seg_len, tps,
+                       ntiles, nseg, (const uint32_t*)ctx->d_tile_off, (const uint64_t*)ctx->d_super_base);
     LRC_HIP(hipGetLastError());
     return LRC_OK;
 }
@@ -714,7 +768,7 @@ int lrc_compact(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_compact
     if (!n) return LRC_OK;
     if (!io->t) return fail(LRC_ERR_INVALID_ARG, "lrc_compact: t is NULL");
     LRC_HIP(hipSetDevice(ctx->device));
-    DevBuf t, p3, sem, ins, inc, cnt, op3, osem, oins, oinc, oidx;
+    DevBuf t, p3, sem, ins, inc, cnt, op3, osem, oins, oinc, oidx, oxyzl;
     lrc_compact_io d{};
     auto up = [&](DevBuf& b, const void* src, size_t bytes, const void** dst) -> int {
         LRC_HIP(hipMalloc(&b.p, bytes));
@@ -734,6 +788,7 @@ int lrc_compact(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_compact
     if (io->out_ins) { LRC_HIP(hipMalloc(&oins.p, n * 2)); d.out_ins = (uint16_t*)oins.p; }
     if (io->out_incident_deg) { LRC_HIP(hipMalloc(&oinc.p, n * 8)); d.out_incident_deg = (double*)oinc.p; }
     if (io->out_index) { LRC_HIP(hipMalloc(&oidx.p, n * 4)); d.out_index = (uint32_t*)oidx.p; }
+    if (io->out_xyzl) { LRC_HIP(hipMalloc(&oxyzl.p, n * 16)); d.out_xyzl = (float*)oxyzl.p; }
     if ((rc = lrc_compact_dev(ctx, nseg, seg_len, &d, nullptr))) return rc;
     LRC_HIP(hipDeviceSynchronize());
     std::vector<uint64_t> counts(nseg);
@@ -749,6 +804,7 @@ int lrc_compact(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_compact
         if (io->out_incident_deg)
             LRC_HIP(hipMemcpy(io->out_incident_deg, d.out_incident_deg, K * 8, hipMemcpyDeviceToHost));
         if (io->out_index) LRC_HIP(hipMemcpy(io->out_index, d.out_index, K * 4, hipMemcpyDeviceToHost));
+        if (io->out_xyzl) LRC_HIP(hipMemcpy(io->out_xyzl, d.out_xyzl, K * 16, hipMemcpyDeviceToHost));
     }
     return LRC_OK;
 }

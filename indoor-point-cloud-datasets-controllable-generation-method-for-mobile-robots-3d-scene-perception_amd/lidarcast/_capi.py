@@ -33,7 +33,7 @@ SYMBOLS = (
 class LrcHits(C.Structure):
     _fields_ = [("t", C.c_void_p), ("prim", C.c_void_p), ("normal3", C.c_void_p),
                 ("point3", C.c_void_p), ("sem", C.c_void_p), ("ins", C.c_void_p),
-                ("incident_deg", C.c_void_p)]
+                ("incident_deg", C.c_void_p), ("tile_count", C.c_void_p)]
 
 
 class LrcSceneInfo(C.Structure):
@@ -46,9 +46,9 @@ class LrcSceneInfo(C.Structure):
 
 class LrcCompactIO(C.Structure):
     _fields_ = [("t", C.c_void_p), ("point3", C.c_void_p), ("sem", C.c_void_p), ("ins", C.c_void_p),
-                ("incident_deg", C.c_void_p), ("counts", C.c_void_p), ("out_point3", C.c_void_p),
-                ("out_sem", C.c_void_p), ("out_ins", C.c_void_p), ("out_incident_deg", C.c_void_p),
-                ("out_index", C.c_void_p)]
+                ("incident_deg", C.c_void_p), ("tile_count", C.c_void_p), ("counts", C.c_void_p),
+                ("out_point3", C.c_void_p), ("out_sem", C.c_void_p), ("out_ins", C.c_void_p),
+                ("out_incident_deg", C.c_void_p), ("out_index", C.c_void_p), ("out_xyzl", C.c_void_p)]
 
 
 _lib = None

@@ -52,7 +52,7 @@ class Context:
 
     # ---- compaction -----------------------------------------------------------------------------
     def compact(self, t, seg_len, point3=None, sem=None, ins=None, incident_deg=None,
-                want_index=False):
+                want_index=False, want_xyzl=False):
         """Stable compaction of finite-t entries; returns dict(counts, point3, sem, ins, ...)."""
         t = np.ascontiguousarray(t, dtype=np.float32).reshape(-1)
         seg_len = int(seg_len)
@@ -84,6 +84,9 @@ class Context:
         if want_index:
             outs["index"] = np.empty(n, dtype=np.uint32)
             io.out_index = outs["index"].ctypes.data
+        if want_xyzl:
+            outs["xyzl"] = np.empty((n, 4), dtype=np.float32)
+            io.out_xyzl = outs["xyzl"].ctypes.data
         total = C.c_uint64(0)
         check(self._lib.lrc_compact(self._h, nseg, seg_len, C.byref(io), C.byref(total)), "lrc_compact")
         k = int(total.value)
@@ -102,7 +105,7 @@ class DeviceHits:
     """Fixed-stride per-ray records in HBM (torch tensors), n entries."""
 
     _TORCH = {"t": "float32", "prim": "int32", "normal3": "float32", "point3": "float32",
-              "sem": "int16", "ins": "int16", "incident_deg": "float64"}
+              "sem": "int16", "ins": "int16", "incident_deg": "float64", "tile_count": "int32"}
 
     def __init__(self, n, device, want=("t", "prim", "normal3", "point3", "sem", "ins")):
         import torch
@@ -111,6 +114,8 @@ class DeviceHits:
         self.tensors = {}
         for a in self.want:
             shape = (self.n, 3) if a.endswith("3") else (self.n,)
+            if a == "tile_count":          # kept rays per aligned run of 64 outputs (feeds compact_dev)
+                shape = ((self.n + 63) // 64,)
             self.tensors[a] = torch.empty(shape, dtype=getattr(torch, self._TORCH[a]), device=device)
         self.struct = LrcHits()
         for a in self.want:
@@ -120,7 +125,8 @@ class DeviceHits:
         return self.tensors[k]
 
     def bytes_per_ray(self):
-        return sum(t.element_size() * (3 if a.endswith("3") else 1) for a, t in self.tensors.items())
+        return sum(t.element_size() * (3 if a.endswith("3") else 1) for a, t in self.tensors.items()
+                   if a != "tile_count")
 
 
 class Scene:

@@ -2,9 +2,9 @@
 
 The scan shards embarrassingly: waypoints are independent (reference loop, s3dis_simulator.py:254-288,
 carries no state between iterations except the frame order).  Each rank scans a contiguous block of
-poses against its own replica of the scene; one all-gather of the fixed-stride, locally compacted
-cloud (RCCL over xGMI on GPUs, gloo in the CPU tests) assembles the scene point cloud in exactly the
-order of ``np.vstack(frames)`` (containers/s3dis_sim_scene.py:326,362).
+poses against its own replica of the scene; one all-gather of the fixed-size slab of locally compacted
+16-byte rows (x, y, z, label bits) -- RCCL over xGMI on GPUs, gloo in the CPU tests -- assembles the
+scene point cloud in exactly the order of ``np.vstack(frames)`` (containers/s3dis_sim_scene.py:326,362).
 """
 import numpy as np
 
@@ -18,39 +18,58 @@ def shard_bounds(num_poses, world_size):
     return b
 
 
-def gather_cloud(local_points, local_labels, local_counts, max_local, dist, device=None):
-    """All-gather a rank's compacted cloud.
+class CloudGather:
+    """Reusable buffers for the per-step all-gather.
 
-    local_points (K_r,3) float32 / local_labels (K_r,) int32 (sem | ins<<16) / local_counts: per-pose
-    hit counts of this rank (torch tensors).  Every rank contributes a fixed-size slab of ``max_local``
-    rows (RCCL has no all-gather-v); the valid prefix lengths travel in a second, tiny all-gather.
-    Returns (points (K,3), labels (K,), per_pose_counts (P,)) assembled in rank -> pose -> ray order.
+    ``slab`` is this rank's (max_local, 4) float32 send buffer: the compaction writes its rows straight
+    into it (lrc_compact_io.out_xyzl), rows past the rank's count are don't-care.  ``counts`` is the
+    rank's (max_poses,) int64 per-pose hit counts.  Every rank contributes the same fixed sizes because
+    RCCL has no all-gather-v; the valid prefix lengths travel in the second, tiny all-gather.
     """
+
+    def __init__(self, max_local, max_poses, dist, device):
+        import torch
+        self.dist, self.world = dist, dist.get_world_size()
+        self.max_local, self.max_poses = int(max_local), int(max_poses)
+        self.slab = torch.zeros((self.max_local, 4), dtype=torch.float32, device=device)
+        self.counts = torch.zeros(self.max_poses, dtype=torch.int64, device=device)
+        self.all_rows = torch.empty((self.world * self.max_local, 4), dtype=torch.float32, device=device)
+        self.all_counts = torch.empty(self.world * self.max_poses, dtype=torch.int64, device=device)
+
+    def gather(self):
+        """Enqueue the two all-gathers (no host synchronisation)."""
+        self.dist.all_gather_into_tensor(self.all_rows, self.slab)
+        self.dist.all_gather_into_tensor(self.all_counts, self.counts)
+
+    def assemble(self, poses_per_rank=None):
+        """(points (K,3) f32, labels (K,) i32, per-pose counts) in rank -> pose -> ray order (host sync)."""
+        import torch
+        call = self.all_counts.view(self.world, self.max_poses).cpu()
+        pts, labs, counts = [], [], []
+        for r in range(self.world):
+            npose = self.max_poses if poses_per_rank is None else int(poses_per_rank[r])
+            c = call[r, :npose]
+            kr = int(c.sum())
+            seg = self.all_rows[r * self.max_local:r * self.max_local + kr]
+            pts.append(seg[:, :3])
+            labs.append(seg[:, 3].contiguous().view(torch.int32))
+            counts.append(c)
+        return torch.cat(pts), torch.cat(labs), torch.cat(counts)
+
+
+def gather_cloud(local_points, local_labels, local_counts, max_local, dist, device=None):
+    """One-shot convenience form: all-gather a rank's compacted cloud given as separate tensors.
+    Returns (points (K,3), labels (K,), per_pose_counts (P,)) assembled in rank -> pose -> ray order."""
     import torch
-    world = dist.get_world_size()
     dev = local_points.device if device is None else device
-    k = int(local_points.shape[0])
-    slab = torch.zeros((max_local, 4), dtype=torch.float32, device=dev)
-    slab[:k, :3] = local_points
-    slab[:k, 3] = local_labels.view(torch.float32) if local_labels.dtype == torch.int32 else local_labels
-    out = torch.empty((world * max_local, 4), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(out, slab)
+    world = dist.get_world_size()
     npose = torch.tensor([local_counts.numel()], dtype=torch.int64, device=dev)
     nposes = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(nposes, npose)
-    pmax = int(nposes.max().item())
-    cpad = torch.zeros(pmax, dtype=torch.int64, device=dev)
-    cpad[:local_counts.numel()] = local_counts.to(torch.int64)
-    call = torch.empty(world * pmax, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(call, cpad)
-    call = call.view(world, pmax).cpu()
-    nposes = nposes.cpu()
-    pts, labs, counts = [], [], []
-    for r in range(world):
-        c = call[r, :int(nposes[r])]
-        kr = int(c.sum())
-        seg = out[r * max_local:r * max_local + kr]
-        pts.append(seg[:, :3])
-        labs.append(seg[:, 3].contiguous().view(torch.int32))
-        counts.append(c)
-    return torch.cat(pts), torch.cat(labs), torch.cat(counts)
+    g = CloudGather(max_local, int(nposes.max().item()), dist, dev)
+    k = int(local_points.shape[0])
+    g.slab[:k, :3] = local_points
+    g.slab[:k, 3] = local_labels.view(torch.float32) if local_labels.dtype == torch.int32 else local_labels
+    g.counts[:local_counts.numel()] = local_counts.to(torch.int64)
+    g.gather()
+    return g.assemble(nposes.cpu())

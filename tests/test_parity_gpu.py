@@ -279,7 +279,7 @@ def test_scan_poses_matches_per_pose_calls(engine):
 
 def test_compaction_matches_numpy(ctx):
     rng = np.random.default_rng(0)
-    for nseg, seg_len in ((1, 1), (3, 1000), (5, 256), (2, 4097), (7, 63)):
+    for nseg, seg_len in ((1, 1), (3, 1000), (5, 256), (2, 4097), (7, 63), (3, 64), (40, 1920), (2, 70001)):
         n = nseg * seg_len
         t = rng.uniform(0, 10, n).astype(np.float32)
         t[rng.random(n) < 0.37] = np.inf
@@ -287,7 +287,8 @@ def test_compaction_matches_numpy(ctx):
         sem = rng.integers(0, 13, n).astype(np.uint16)
         ins = rng.integers(0, 60000, n).astype(np.uint16)
         ang = rng.uniform(0, 90, n)
-        r = ctx.compact(t, seg_len, point3=pts, sem=sem, ins=ins, incident_deg=ang, want_index=True)
+        r = ctx.compact(t, seg_len, point3=pts, sem=sem, ins=ins, incident_deg=ang, want_index=True,
+                        want_xyzl=True)
         keep = np.isfinite(t)
         assert r["total"] == keep.sum()
         assert np.array_equal(r["counts"], keep.reshape(nseg, seg_len).sum(1))
@@ -295,6 +296,9 @@ def test_compaction_matches_numpy(ctx):
         assert np.array_equal(r["sem"], sem[keep]) and np.array_equal(r["ins"], ins[keep])
         assert_bit_equal(r["incident_deg"], ang[keep])
         assert np.array_equal(r["index"], np.tile(np.arange(seg_len), nseg)[keep].astype(np.uint32))
+        assert_bit_equal(r["xyzl"][:, :3], pts[keep])
+        assert np.array_equal(r["xyzl"][:, 3].copy().view(np.uint32),
+                              sem[keep].astype(np.uint32) | (ins[keep].astype(np.uint32) << 16))
     r = ctx.compact(np.full(300, np.inf, np.float32), 100, point3=np.zeros((300, 3), np.float32))
     assert r["total"] == 0 and r["point3"].shape == (0, 3)
 
@@ -349,3 +353,45 @@ def test_simulator_scan_stage(tmp_path):
                 return rays
         ref_pts, _ = np_oracle.lidar_intersect_mesh(om, Frozen(), threads=8)
         assert_bit_equal(sc2.frames[i].points, ref_pts)
+
+
+def test_device_path_fused_tile_counts_and_packed_rows(ctx):
+    """The bench's device-resident step: scan_poses_dev (with per-wave keep counts) -> compact_dev into
+    16-byte rows, against the host-array API of the same library and the oracle's hit count."""
+    import torch
+    import lidarcast
+    from lidarcast import synth
+    from lidarcast._capi import LrcCompactIO
+    from lidar import IndoorLidar
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=4, seed=5, cell=0.04)
+    scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
+    for lines, width, max_range in ((4, 256, 2.0), (3, 100, 20.0)):       # 1024 (tiles line up) and 300 rays per pose
+        k = sensor_small(lines=lines, width=width, max_range=max_range)
+        poses = np.stack([pose(1.0 + 0.5 * i, 1.5, 1.0) for i in range(5)])
+        dirs = IndoorLidar(k, np.eye(4)).sensor_directions()
+        P, N = len(poses), len(dirs)
+        ref = scene.scan_poses(poses, dirs, k.max_range, want=("t", "point3", "sem", "ins"))
+        dev = torch.device("cuda", 0)
+        hits = lidarcast.DeviceHits(P * N, dev, want=("t", "point3", "sem", "ins", "tile_count"))
+        d_poses = torch.from_numpy(poses.reshape(P, 16)).to(dev)
+        d_dirs = torch.from_numpy(dirs).to(dev)
+        rows = torch.zeros((P * N, 4), dtype=torch.float32, device=dev)
+        counts = torch.zeros(P, dtype=torch.int64, device=dev)
+        io = LrcCompactIO()
+        io.t, io.point3, io.sem, io.ins = (hits[a].data_ptr() for a in ("t", "point3", "sem", "ins"))
+        io.tile_count, io.counts, io.out_xyzl = hits["tile_count"].data_ptr(), counts.data_ptr(), rows.data_ptr()
+        st = torch.cuda.current_stream().cuda_stream
+        scene.scan_poses_dev(d_poses, d_dirs, hits, k.max_range, st)
+        ctx.compact_dev(P, N, io, st)
+        torch.cuda.synchronize()
+        keep = np.isfinite(ref["t"])
+        assert 0 < keep.sum() < P * N or max_range > 10
+        assert np.array_equal(counts.cpu().numpy(), keep.reshape(P, N).sum(1))
+        got = rows.cpu().numpy()[:keep.sum()]
+        assert_bit_equal(got[:, :3], ref["point3"][keep])
+        lab = ref["sem"][keep].astype(np.uint32) | (ref["ins"][keep].astype(np.uint32) << 16)
+        assert np.array_equal(got[:, 3].copy().view(np.uint32), lab)
+        tc = hits["tile_count"].cpu().numpy()
+        pad = np.zeros(len(tc) * 64, bool)
+        pad[:P * N] = keep
+        assert np.array_equal(tc, pad.reshape(-1, 64).sum(1))

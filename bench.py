@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scene", default=SCENE)
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="run the N>1 code path (RCCL all-gather, double buffering) with world size 1 and check "
+                         "the assembled cloud against the local one")
     args = ap.parse_args()
 
     import torch
@@ -140,9 +143,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.dist_selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     # ---- scene (replicated) and inputs, resident in HBM before the timed region ----
     mesh = synth.make_scene(args.scene)
@@ -157,25 +161,35 @@ def main():
     d_poses = torch.from_numpy(poses.reshape(P, 16)).to(dev)
     d_dirs = torch.from_numpy(dirs).to(dev)
     hits = lidarcast.DeviceHits(n, dev, want=("t", "prim", "normal3", "point3", "sem", "ins", "tile_count"))
-    # scene cloud: compacted 16-byte rows (x, y, z, sem|ins<<16) in np.vstack order + per-pose counts
-    if world > 1:
+    # scene cloud: compacted 16-byte rows (x, y, z, sem|ins<<16) in np.vstack order + per-pose counts.
+    # N > 1: two send/receive buffer sets, so that the all-gather of scan i overlaps the trace of scan i+1.
+    dist_path = world > 1 or args.dist_selftest
+    if dist_path:
         from lidarcast.distributed import CloudGather
-        gather = CloudGather(n, P, dist, dev)
-        cloud, counts = gather.slab, gather.counts
+        gathers = [CloudGather(n, P, dist, dev) for _ in range(2)]
+        bufs = [(g.slab, g.counts) for g in gathers]
     else:
-        gather = None
-        cloud = torch.empty((n, 4), dtype=torch.float32, device=dev)
-        counts = torch.zeros(P, dtype=torch.int64, device=dev)
-    io = LrcCompactIO()
-    io.t, io.point3 = hits["t"].data_ptr(), hits["point3"].data_ptr()
-    io.sem, io.ins = hits["sem"].data_ptr(), hits["ins"].data_ptr()
-    io.tile_count = hits["tile_count"].data_ptr()
-    io.counts, io.out_xyzl = counts.data_ptr(), cloud.data_ptr()
+        gathers = None
+        bufs = [(torch.empty((n, 4), dtype=torch.float32, device=dev), torch.zeros(P, dtype=torch.int64, device=dev))]
+    ios = []
+    for cloud, cnt in bufs:
+        io = LrcCompactIO()
+        io.t, io.point3 = hits["t"].data_ptr(), hits["point3"].data_ptr()
+        io.sem, io.ins = hits["sem"].data_ptr(), hits["ins"].data_ptr()
+        io.tile_count = hits["tile_count"].data_ptr()
+        io.counts, io.out_xyzl = cnt.data_ptr(), cloud.data_ptr()
+        ios.append(io)
+    counts = bufs[0][1]
     stream = torch.cuda.current_stream().cuda_stream
 
     k_events = []
+    state = {"i": 0}
 
     def step(timed):
+        i = state["i"] % len(ios)
+        state["i"] += 1
+        if gathers is not None:
+            gathers[i].wait()        # the collective that last used this buffer set must have finished
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -183,11 +197,14 @@ def main():
         if timed:
             e1.record()
             k_events.append((e0, e1))
-        ctx.compact_dev(P, N, io, stream)
-        if gather is not None:
-            gather.gather()          # one RCCL all-gather of the rows (+ the tiny one of the counts)
+        ctx.compact_dev(P, N, ios[i], stream)
+        if gathers is not None:
+            gathers[i].gather(async_op=True)     # ONE RCCL all-gather per scan (rows + counts in one slab)
 
     def barrier():
+        if gathers is not None:
+            for g in gathers:
+                g.wait()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -205,6 +222,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    if args.dist_selftest:
+        pts, labs, cnts = gathers[0].assemble()
+        k = int(gathers[0].counts.sum().item())
+        assert pts.shape[0] == k * world and torch.equal(pts[:k], gathers[0].slab[:k, :3]), "gathered cloud differs"
+        assert torch.equal(cnts[:P], gathers[0].counts.cpu())
+        print(f"dist selftest ok: {k} rows gathered, world {world}", file=sys.stderr)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in k_events]))
     hits_total = int(counts.sum().item())
     total_rays = n * world * args.steps
@@ -246,7 +269,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(mesh, sensor, poses)
             res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or args.dist_selftest:
         dist.destroy_process_group()
 
 

@@ -19,38 +19,47 @@ def shard_bounds(num_poses, world_size):
 
 
 class CloudGather:
-    """Reusable buffers for the per-step all-gather.
+    """Reusable buffers for the per-scan all-gather (exactly one collective per scan).
 
-    ``slab`` is this rank's (max_local, 4) float32 send buffer: the compaction writes its rows straight
-    into it (lrc_compact_io.out_xyzl), rows past the rank's count are don't-care.  ``counts`` is the
-    rank's (max_poses,) int64 per-pose hit counts.  Every rank contributes the same fixed sizes because
-    RCCL has no all-gather-v; the valid prefix lengths travel in the second, tiny all-gather.
+    ``slab`` is this rank's (max_local + tail, 4) float32 send buffer.  Rows [0, max_local) receive the
+    compacted cloud straight from the compaction kernel (lrc_compact_io.out_xyzl); rows past the rank's
+    hit count are don't-care.  The tail rows hold the rank's per-pose hit counts as int64 (``counts`` is
+    a view of them; lrc_compact_io.counts points there), so the prefix lengths travel inside the same
+    collective.  Every rank contributes the same fixed size because RCCL has no all-gather-v.
     """
 
     def __init__(self, max_local, max_poses, dist, device):
         import torch
         self.dist, self.world = dist, dist.get_world_size()
         self.max_local, self.max_poses = int(max_local), int(max_poses)
-        self.slab = torch.zeros((self.max_local, 4), dtype=torch.float32, device=device)
-        self.counts = torch.zeros(self.max_poses, dtype=torch.int64, device=device)
-        self.all_rows = torch.empty((self.world * self.max_local, 4), dtype=torch.float32, device=device)
-        self.all_counts = torch.empty(self.world * self.max_poses, dtype=torch.int64, device=device)
+        self.tail = (self.max_poses * 8 + 15) // 16
+        self.rows = self.max_local + self.tail
+        self.slab = torch.zeros((self.rows, 4), dtype=torch.float32, device=device)
+        self.counts = self.slab[self.max_local:].view(-1).view(torch.int64)[:self.max_poses]
+        self.all_rows = torch.empty((self.world * self.rows, 4), dtype=torch.float32, device=device)
+        self.work = None
 
-    def gather(self):
-        """Enqueue the two all-gathers (no host synchronisation)."""
-        self.dist.all_gather_into_tensor(self.all_rows, self.slab)
-        self.dist.all_gather_into_tensor(self.all_counts, self.counts)
+    def gather(self, async_op=False):
+        """Enqueue the all-gather.  async_op=True returns at once; ``wait()`` before touching the buffers."""
+        self.work = self.dist.all_gather_into_tensor(self.all_rows, self.slab, async_op=async_op)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
 
     def assemble(self, poses_per_rank=None):
         """(points (K,3) f32, labels (K,) i32, per-pose counts) in rank -> pose -> ray order (host sync)."""
         import torch
-        call = self.all_counts.view(self.world, self.max_poses).cpu()
+        self.wait()
+        per_rank = self.all_rows.view(self.world, self.rows, 4)
+        call = per_rank[:, self.max_local:].reshape(self.world, -1).view(torch.int64)[:, :self.max_poses].cpu()
         pts, labs, counts = [], [], []
         for r in range(self.world):
             npose = self.max_poses if poses_per_rank is None else int(poses_per_rank[r])
             c = call[r, :npose]
             kr = int(c.sum())
-            seg = self.all_rows[r * self.max_local:r * self.max_local + kr]
+            seg = per_rank[r, :kr]
             pts.append(seg[:, :3])
             labs.append(seg[:, 3].contiguous().view(torch.int32))
             counts.append(c)

@@ -15,10 +15,13 @@
 #include "lrc_bvh.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <deque>
+#include <future>
+#include <thread>
 
 namespace lrc {
 namespace {
@@ -60,13 +63,24 @@ inline int ceil_log2_u64(uint64_t x) {   // smallest k with 2^k >= x  (x >= 1)
     return k;
 }
 
+// The recursion forks std::async tasks near the root (disjoint prim ranges, nodes taken from one
+// pre-sized pool through an atomic counter).  Temporary node numbers then depend on thread timing, but
+// the TREE does not, and the final relayout renumbers nodes from the structure alone: the output is
+// deterministic.
 struct Builder {
     std::vector<Prim> prims;
-    std::vector<TmpNode> nodes;
+    std::vector<TmpNode> nodes;              // pool, sized up front
+    std::atomic<int64_t> next_node{0};
     int max_leaf = kMaxLeaf;
-    uint32_t max_depth = 0;
-    uint32_t max_leaf_seen = 0;
-    uint64_t num_leaves = 0;
+    int fork_depth = 0;                      // fork while depth < fork_depth
+    std::atomic<uint32_t> max_depth{0};
+    std::atomic<uint32_t> max_leaf_seen{0};
+    std::atomic<uint64_t> num_leaves{0};
+
+    static void atomic_max(std::atomic<uint32_t>& a, uint32_t v) {
+        uint32_t cur = a.load(std::memory_order_relaxed);
+        while (cur < v && !a.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
+    }
 
     // height of a median-split subtree over n prims (0 = it is a single leaf)
     int median_height(uint64_t n) const {
@@ -78,9 +92,9 @@ struct Builder {
 
     int64_t make_leaf(uint64_t begin, uint64_t end, int depth) {
         uint64_t cnt = end - begin;
-        max_depth = std::max<uint32_t>(max_depth, (uint32_t)depth);
-        max_leaf_seen = std::max<uint32_t>(max_leaf_seen, (uint32_t)cnt);
-        ++num_leaves;
+        atomic_max(max_depth, (uint32_t)depth);
+        atomic_max(max_leaf_seen, (uint32_t)cnt);
+        num_leaves.fetch_add(1, std::memory_order_relaxed);
         return ~(int64_t)(begin * 8 + cnt);
     }
 
@@ -163,15 +177,18 @@ struct Builder {
                              });
         }
 
-        const int64_t me = (int64_t)nodes.size();
-        nodes.emplace_back();
-        {
-            TmpNode& nd = nodes[me];
-            nd.box[0] = range_box(begin, mid);
-            nd.box[1] = range_box(mid, end);
+        const int64_t me = next_node.fetch_add(1, std::memory_order_relaxed);
+        nodes[me].box[0] = range_box(begin, mid);
+        nodes[me].box[1] = range_box(mid, end);
+        int64_t c0, c1;
+        if (depth < fork_depth && n >= 20000) {
+            auto left = std::async(std::launch::async, [this, begin, mid, depth] { return build(begin, mid, depth + 1); });
+            c1 = build(mid, end, depth + 1);
+            c0 = left.get();
+        } else {
+            c0 = build(begin, mid, depth + 1);
+            c1 = build(mid, end, depth + 1);
         }
-        int64_t c0 = build(begin, mid, depth + 1);
-        int64_t c1 = build(mid, end, depth + 1);
         nodes[me].child[0] = c0;
         nodes[me].child[1] = c1;
         return me;
@@ -207,8 +224,14 @@ void build_bvh(const float* verts3, uint64_t V, const uint32_t* tris3, uint64_t 
     }
     for (int k = 0; k < 3; ++k) { o.bounds_lo[k] = all.lo[k]; o.bounds_hi[k] = all.hi[k]; }
 
-    b.nodes.reserve(T);
+    b.nodes.resize(T + 1);                   // inner nodes < leaves <= T
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        int threads = opt.threads > 0 ? opt.threads : (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+        while ((1 << b.fork_depth) < threads) ++b.fork_depth;      // 2^fork_depth tasks
+    }
     int64_t root = b.build(0, T, 0);
+    b.nodes.resize((size_t)b.next_node.load());
     if (root < 0) {
         // the whole mesh is one leaf: wrap it so that node 0 is always an inner node
         TmpNode nd;
@@ -217,7 +240,7 @@ void build_bvh(const float* verts3, uint64_t V, const uint32_t* tris3, uint64_t 
         nd.child[0] = root;
         nd.child[1] = ~(int64_t)0;   // empty leaf: slot 0, count 0
         b.nodes.push_back(nd);
-        b.max_depth = std::max<uint32_t>(b.max_depth, 1);
+        Builder::atomic_max(b.max_depth, 1);
         root = 0;
     }
 
@@ -248,10 +271,10 @@ void build_bvh(const float* verts3, uint64_t V, const uint32_t* tris3, uint64_t 
     }
 
     o.num_nodes = nn;
-    o.num_leaves = b.num_leaves;
+    o.num_leaves = b.num_leaves.load();
     o.num_slots = T;
-    o.max_depth = b.max_depth;
-    o.max_leaf_size = b.max_leaf_seen;
+    o.max_depth = b.max_depth.load();
+    o.max_leaf_size = b.max_leaf_seen.load();
     o.nodes.assign(nn * kNodeFloats, 0.0f);
     for (uint64_t i = 0; i < nn; ++i) {
         const TmpNode& nd = b.nodes[old_of_new[i]];

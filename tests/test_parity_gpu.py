@@ -4,6 +4,8 @@ Bars: hit mask, surviving ray indices and triangle ids 
 bit-exact (the allowed tolerance is 1e-5 m; the implementation meets 0 ulp and the tests assert it);
 float64 incident angles within 1e-9 degree (device acos vs numpy's libm).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -395,3 +397,88 @@ def test_device_path_fused_tile_counts_and_packed_rows(ctx):
         pad = np.zeros(len(tc) * 64, bool)
         pad[:P * N] = keep
         assert np.array_equal(tc, pad.reshape(-1, 64).sum(1))
+
+
+def test_full_size_c3_properties(ctx):
+    """BASELINE config C3 at full size (64 poses x 65 536 rays, T = 605 328), device-resident path.
+    Size-independent properties + four poses checked ray by ray against the oracle."""
+    import hashlib
+    import torch
+    import bench
+    import lidarcast
+    from lidar import IndoorLidar, create_lidar
+    from lidarcast import synth
+    from lidarcast._capi import LrcCompactIO
+    from oracle import np_oracle
+    from oracle.c_oracle import OracleMesh
+    mesh = synth.make_scene(bench.SCENE)
+    scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
+    sensor = bench.c3_sensor()
+    poses = bench.c3_poses(0, 1)
+    dirs = IndoorLidar(sensor, np.eye(4)).sensor_directions()
+    P, N = len(poses), len(dirs)
+    dev = torch.device("cuda", 0)
+    hits = lidarcast.DeviceHits(P * N, dev, want=("t", "prim", "normal3", "point3", "sem", "ins", "tile_count"))
+    d_poses, d_dirs = torch.from_numpy(poses.reshape(P, 16)).to(dev), torch.from_numpy(dirs).to(dev)
+    rows = torch.zeros((P * N, 4), dtype=torch.float32, device=dev)
+    counts = torch.zeros(P, dtype=torch.int64, device=dev)
+    io = LrcCompactIO()
+    io.t, io.point3, io.sem, io.ins = (hits[a].data_ptr() for a in ("t", "point3", "sem", "ins"))
+    io.tile_count, io.counts, io.out_xyzl = hits["tile_count"].data_ptr(), counts.data_ptr(), rows.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    digests = []
+    for _ in range(2):                                   # idempotence: two scans, identical bytes
+        scene.scan_poses_dev(d_poses, d_dirs, hits, sensor.max_range, st)
+        ctx.compact_dev(P, N, io, st)
+        torch.cuda.synchronize()
+        k = int(counts.sum().item())
+        h = hashlib.sha256()
+        for a in ("t", "prim", "normal3", "point3", "sem", "ins"):
+            h.update(hits[a].cpu().numpy().tobytes())
+        h.update(rows[:k].cpu().numpy().tobytes())
+        digests.append(h.hexdigest())
+    assert digests[0] == digests[1]
+    t = hits["t"].cpu().numpy().reshape(P, N)
+    prim = hits["prim"].cpu().numpy().view(np.uint32).reshape(P, N)
+    pts = hits["point3"].cpu().numpy().reshape(P, N, 3)
+    nrm = hits["normal3"].cpu().numpy().reshape(P, N, 3)
+    hit = np.isfinite(t)
+    assert hit.mean() > 0.999 and (prim[~hit] == 0xFFFFFFFF).all() and (prim[hit] < len(mesh.triangles)).all()
+    assert np.array_equal(counts.cpu().numpy(), hit.sum(1)) and k == hit.sum()
+    lo, hi = mesh.vertices.min(0) - 1e-3, mesh.vertices.max(0) + 1e-3
+    assert (pts[hit] >= lo).all() and (pts[hit] <= hi).all()             # every hit lies inside the room
+    assert np.abs(np.linalg.norm(nrm[hit], axis=1) - 1).max() < 1e-5
+    assert np.array_equal(hits["sem"].cpu().numpy().view(np.uint16).reshape(P, N)[hit], mesh.triangle_sem[prim[hit]])
+    rng = np.linalg.norm(pts - poses[:, None, :3, 3], axis=2)
+    assert (rng[hit] < sensor.max_range).all() and np.abs(rng[hit] - t[hit]).max() < 1e-4   # unit directions
+    assert np.array_equal(rows[:k, :3].cpu().numpy(), pts[hit])         # cloud = np.vstack of the frames
+    om = OracleMesh(mesh.vertices, mesh.triangles).build()
+    for p in (0, 21, 42, 63):
+        lidar = create_lidar(sensor, poses[p])
+        ref_pts, _, ref_idx = np_oracle.lidar_intersect_mesh(om, lidar, threads=16, return_index=True)
+        assert np.array_equal(np.flatnonzero(hit[p]), ref_idx)
+        assert_bit_equal(pts[p][hit[p]], ref_pts)
+        tr, pr = om.cast(lidar.get_rays(), threads=16)
+        assert_bit_equal(t[p][hit[p]], tr[ref_idx])
+        assert np.array_equal(prim[p][hit[p]], pr[ref_idx])
+
+
+def test_bench_contract():
+    """bench.py prints one JSON line with the driver's keys plus roofline and cpu_baseline objects."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, check=True).stdout
+    line = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    r = json.loads(line[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["unit"] == "rays/s" and r["vs_baseline"] is None
+    assert "workload" in r["config"] and r["value"] > 1e8
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r["roofline"])
+    assert abs(r["roofline"]["frac"] - r["roofline"]["achieved"] / r["roofline"]["peak"]) < 1e-9
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(r["cpu_baseline"]) and r["cpu_baseline"]["kind"] == "port"

@@ -128,6 +128,20 @@ int lrc_cast_dev(lrc_scene* scene, const float* d_rays6, uint64_t num_rays,
                  const double* center3 /* HOST pointer, 3 doubles or NULL */, double max_range,
                  const lrc_hits* d_out, void* stream);
 
+/* ---- cast: explicit rays of several poses in one launch ------------------------------------------
+ * rays6 holds the rays of S poses back to back (ragged: the dual-axis sensor drops ~2 % of its rays per
+ * pose, lidar/indoor_lidar.py:292-294); seg_offsets (S+1 entries, first 0, last num_rays) delimits them
+ * and centers3 (S,3) gives each pose's range-filter centre.  Per ray exactly lrc_cast with its pose's
+ * centre.  Replaces the per-waypoint loop body (s3dis_simulator.py:254-264) for sensors whose rays are
+ * generated on the host. */
+int lrc_cast_segments(lrc_scene* scene, const float* rays6, uint64_t num_rays,
+                      const uint64_t* seg_offsets, uint64_t num_segments, const double* centers3,
+                      double max_range, const lrc_hits* out);
+int lrc_cast_segments_dev(lrc_scene* scene, const float* d_rays6, uint64_t num_rays,
+                          const uint64_t* d_seg_offsets, uint64_t num_segments,
+                          const double* d_centers3, double max_range, const lrc_hits* d_out,
+                          void* stream);
+
 /* ---- scan: pose-batched, rays generated in the kernel -------------------------------------------
  * poses16: (P,16) float64 row-major 4x4 sensor poses (Waypoint.to_pose_matrix,
  *          trajectory/trajectory_generator.py:30-44).

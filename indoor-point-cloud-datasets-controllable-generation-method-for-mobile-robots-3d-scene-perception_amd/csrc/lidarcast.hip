@@ -91,6 +91,9 @@ struct TraceParams {
     uint32_t num_nodes;
     // inputs
     const float* rays6;        // explicit rays (GEN = false)
+    const uint64_t* seg_offsets;   // explicit rays in S segments (poses): (S+1) ray offsets, or NULL
+    const double* seg_centers3;    // (S,3) range-filter centres of the segments
+    uint32_t num_segments;
     const double* poses16;     // GEN = true
     const double* dirs3;       // GEN = true
     uint64_t rays_per_pose;
@@ -142,7 +145,16 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
         const float* r = p.rays6 + gid * 6;
         o.x = r[0]; o.y = r[1]; o.z = r[2];
         d.x = r[3]; d.y = r[4]; d.z = r[5];
-        if (p.has_center) { cx = p.cx; cy = p.cy; cz = p.cz; }
+        if (p.seg_offsets) {
+            // rays of several poses back to back: find this ray's pose (largest s with off[s] <= gid)
+            uint32_t lo = 0, hi = p.num_segments;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (p.seg_offsets[mid] <= gid) lo = mid; else hi = mid;
+            }
+            const double* c = p.seg_centers3 + (size_t)lo * 3;
+            cx = c[0]; cy = c[1]; cz = c[2];
+        } else if (p.has_center) { cx = p.cx; cy = p.cy; cz = p.cz; }
         else { cx = (double)o.x; cy = (double)o.y; cz = (double)o.z; }
     }
 
@@ -622,6 +634,27 @@ int lrc_cast_dev(lrc_scene* s, const float* d_rays6, uint64_t n, const double* c
     return launch_trace(s, p, false, (hipStream_t)stream);
 }
 
+int lrc_cast_segments_dev(lrc_scene* s, const float* d_rays6, uint64_t n, const uint64_t* d_seg_offsets,
+                          uint64_t num_segments, const double* d_centers3, double max_range,
+                          const lrc_hits* d_out, void* stream) {
+    if (!s || !d_out) return fail(LRC_ERR_INVALID_ARG, "lrc_cast_segments_dev: NULL scene or output");
+    if (n && (!d_rays6 || !d_seg_offsets || !d_centers3 || num_segments == 0))
+        return fail(LRC_ERR_INVALID_ARG, "lrc_cast_segments_dev: NULL rays, offsets or centres");
+    if (num_segments > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "lrc_cast_segments_dev: too many segments");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    TraceParams p{};
+    p.rays6 = d_rays6;
+    p.seg_offsets = d_seg_offsets;
+    p.seg_centers3 = d_centers3;
+    p.num_segments = (uint32_t)num_segments;
+    p.total = n;
+    p.rays_per_pose = n ? n : 1;
+    p.has_center = 1;
+    p.max_range = max_range;
+    p.out = *d_out;
+    return launch_trace(s, p, false, (hipStream_t)stream);
+}
+
 int lrc_scan_poses_dev(lrc_scene* s, const double* d_poses16, uint64_t P, const double* d_dirs3,
                        uint64_t N, double max_range, const lrc_hits* d_out, void* stream) {
     if (!s || !d_out) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_poses_dev: NULL scene or output");
@@ -686,6 +719,35 @@ int lrc_cast(lrc_scene* s, const float* rays6, uint64_t n, const double* center3
     int rc = st.alloc(*out, n);
     if (rc) return rc;
     rc = lrc_cast_dev(s, (const float*)rays.p, n, center3, max_range, &st.d, nullptr);
+    if (rc) return rc;
+    LRC_HIP(hipDeviceSynchronize());
+    return st.download(*out, n);
+}
+
+int lrc_cast_segments(lrc_scene* s, const float* rays6, uint64_t n, const uint64_t* seg_offsets,
+                      uint64_t num_segments, const double* centers3, double max_range, const lrc_hits* out) {
+    if (!s || !out) return fail(LRC_ERR_INVALID_ARG, "lrc_cast_segments: NULL scene or output");
+    if (!n) return LRC_OK;
+    if (!rays6 || !seg_offsets || !centers3 || num_segments == 0)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_cast_segments: NULL rays, offsets or centres");
+    if (seg_offsets[0] != 0 || seg_offsets[num_segments] != n)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_cast_segments: offsets must start at 0 and end at num_rays");
+    for (uint64_t k = 0; k < num_segments; ++k)
+        if (seg_offsets[k] > seg_offsets[k + 1])
+            return fail(LRC_ERR_INVALID_ARG, "lrc_cast_segments: offsets must be non-decreasing");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    DevBuf rays, offs, cen;
+    LRC_HIP(hipMalloc(&rays.p, n * 24));
+    LRC_HIP(hipMalloc(&offs.p, (num_segments + 1) * 8));
+    LRC_HIP(hipMalloc(&cen.p, num_segments * 24));
+    LRC_HIP(hipMemcpy(rays.p, rays6, n * 24, hipMemcpyHostToDevice));
+    LRC_HIP(hipMemcpy(offs.p, seg_offsets, (num_segments + 1) * 8, hipMemcpyHostToDevice));
+    LRC_HIP(hipMemcpy(cen.p, centers3, num_segments * 24, hipMemcpyHostToDevice));
+    HitsStage st;
+    int rc = st.alloc(*out, n);
+    if (rc) return rc;
+    rc = lrc_cast_segments_dev(s, (const float*)rays.p, n, (const uint64_t*)offs.p, num_segments,
+                               (const double*)cen.p, max_range, &st.d, nullptr);
     if (rc) return rc;
     LRC_HIP(hipDeviceSynchronize());
     return st.download(*out, n);

@@ -25,7 +25,8 @@ SYMBOLS = (
     "lrc_ctx_create", "lrc_ctx_destroy", "lrc_ctx_synchronize",
     "lrc_scene_create", "lrc_scene_destroy", "lrc_scene_get_info", "lrc_scene_export_bvh",
     "lrc_scene_get_counters",
-    "lrc_cast", "lrc_cast_dev", "lrc_scan_poses", "lrc_scan_poses_dev",
+    "lrc_cast", "lrc_cast_dev", "lrc_cast_segments", "lrc_cast_segments_dev",
+    "lrc_scan_poses", "lrc_scan_poses_dev",
     "lrc_compact", "lrc_compact_dev",
 )
 
@@ -83,6 +84,8 @@ def load():
         "lrc_scene_get_counters": [vp, C.POINTER(u64), C.POINTER(u64)],
         "lrc_cast": [vp, vp, u64, vp, dbl, C.POINTER(LrcHits)],
         "lrc_cast_dev": [vp, vp, u64, vp, dbl, C.POINTER(LrcHits), vp],
+        "lrc_cast_segments": [vp, vp, u64, vp, u64, vp, dbl, C.POINTER(LrcHits)],
+        "lrc_cast_segments_dev": [vp, vp, u64, vp, u64, vp, dbl, C.POINTER(LrcHits), vp],
         "lrc_scan_poses": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcHits)],
         "lrc_scan_poses_dev": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcHits), vp],
         "lrc_compact": [vp, u64, u64, C.POINTER(LrcCompactIO), C.POINTER(u64)],

@@ -212,6 +212,21 @@ class Scene:
         check(self._lib.lrc_cast(self._h, _ptr(rays), n, _ptr(c), float(max_range), C.byref(st)), "lrc_cast")
         return outs
 
+    def cast_segments(self, rays, seg_offsets, centers, max_range, want=ATTRS):
+        """Rays of several poses back to back (ragged), one range-filter centre per pose."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        if rays.ndim != 2 or rays.shape[1] != 6:
+            raise ValueError("rays must be a (N, 6) array.")
+        off = np.ascontiguousarray(seg_offsets, dtype=np.uint64).reshape(-1)
+        cen = np.ascontiguousarray(centers, dtype=np.float64).reshape(-1, 3)
+        if len(off) != len(cen) + 1:
+            raise ValueError("seg_offsets must have one more entry than centers")
+        n = rays.shape[0]
+        outs, st = self._alloc(n, want)
+        check(self._lib.lrc_cast_segments(self._h, _ptr(rays), n, _ptr(off), len(cen), _ptr(cen),
+                                          float(max_range), C.byref(st)), "lrc_cast_segments")
+        return outs
+
     def scan_poses(self, poses, dirs, max_range, want=ATTRS):
         """poses (P,4,4) f64, dirs (N,3) f64 sensor-frame -> dict of (P*N, ...) arrays."""
         poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 16)

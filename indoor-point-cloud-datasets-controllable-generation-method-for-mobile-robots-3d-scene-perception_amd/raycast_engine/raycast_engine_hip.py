@@ -69,7 +69,8 @@ class RaycastEngineHIP(RaycastEngineBase):
         except TypeError:
             ref = None
         if len(self._scenes) >= self._max_cached:
-            self._scenes.pop(next(iter(self._scenes))).__getitem__(2).close()
+            oldest = self._scenes.pop(next(iter(self._scenes)))
+            oldest[2].close()
         self._scenes[key] = (ref, fp, scene)
         return scene
 
@@ -132,6 +133,25 @@ class RaycastEngineHIP(RaycastEngineBase):
         out = scene.scan_poses(poses, dirs, intrinsics.max_range, want=want)
         P, N = poses.shape[0], dirs.shape[0]
         return {k: a.reshape((P, N) + a.shape[1:]) for k, a in out.items()}, N
+
+
+    def scan_lidars(self, lidars, mesh, want=("t", "point3", "incident_deg")):
+        """Several sensor poses whose rays come from the host generator (dual-axis sensor: seeded noise and
+        dropout make the ray sets ragged), cast in ONE launch.  Returns (records dict of flat arrays, offsets):
+        pose i owns records[offsets[i]:offsets[i+1]].  ``get_rays()`` is called in list order, so a seeded
+        global numpy stream is consumed exactly as the reference's per-waypoint loop would."""
+        if len(lidars) == 0:
+            raise ValueError("no lidars given")
+        rays = [l.get_rays() for l in lidars]
+        for r in rays:
+            self._check_rays(r)
+        off = np.zeros(len(rays) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in rays])
+        centers = np.stack([np.asarray(l.pose)[:3, 3] for l in lidars])
+        max_range = lidars[0].intrinsics.max_range
+        scene = self.scene_for(mesh)
+        out = scene.cast_segments(np.concatenate(rays).astype(np.float32), off, centers, max_range, want=want)
+        return out, off.astype(np.int64)
 
 
 class RaycastEngineGPU(RaycastEngineHIP):

@@ -87,18 +87,20 @@ class S3DISSimulator:
             # every pose in one launch; rays generated in the kernel
             rec, n = self.raycast_engine.scan_poses(self.lidar_config, poses_from_waypoints(waypoints), mesh,
                                                     want=("t", "point3", "incident_deg", "sem", "ins"))
+        elif len(waypoints) > 0:
+            # host-generated rays (dual-axis sensor): all poses in one launch, ragged segments
+            lidars = [create_lidar(self.lidar_config, wp.to_pose_matrix()) for wp in waypoints]
+            seg, off = self.raycast_engine.scan_lidars(lidars, mesh, want=("t", "point3", "incident_deg", "sem", "ins"))
         for i, wp in enumerate(waypoints):
             if batched:
                 keep = rec["t"][i] != np.inf
                 points, angles = rec["point3"][i][keep], rec["incident_deg"][i][keep]
                 sem, ins = rec["sem"][i][keep], rec["ins"][i][keep]
             else:
-                lidar = create_lidar(self.lidar_config, wp.to_pose_matrix())
-                res = self.raycast_engine.cast_rays(lidar.get_rays(), mesh, center=lidar.pose[:3, 3],
-                                                    max_range=self.lidar_config.max_range)
-                keep = res["t_hit"] != np.inf
-                points, angles = res["points"][keep], res["incident_angles"][keep]
-                sem, ins = res["semantic"][keep], res["instance"][keep]
+                a, b = off[i], off[i + 1]
+                keep = seg["t"][a:b] != np.inf
+                points, angles = seg["point3"][a:b][keep], seg["incident_deg"][a:b][keep]
+                sem, ins = seg["sem"][a:b][keep], seg["ins"][a:b][keep]
             if self.bug_compatible:
                 angles = np.zeros(len(points))            # reference :266-269
             q = self._quality(points, angles, total, volume)

@@ -482,3 +482,36 @@ def test_bench_contract():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r["roofline"])
     assert abs(r["roofline"]["frac"] - r["roofline"]["achieved"] / r["roofline"]["peak"]) < 1e-9
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(r["cpu_baseline"]) and r["cpu_baseline"]["kind"] == "port"
+
+
+def test_cast_segments_ragged_poses(engine, a1):
+    """BLK2GO poses (ragged ray sets on one seeded stream) in one launch == pose-by-pose calls == oracle."""
+    from lidar import DualAxisLidarIntrinsics, create_lidar
+    from oracle import np_oracle
+    mesh, om = a1
+    k = DualAxisLidarIntrinsics.create_blk2go_dual_axis()
+    poses = [pose(2.0 + 0.5 * i, 3.0, 1.0, yaw=0.2 * i) for i in range(3)]
+    np.random.seed(11)
+    lidars = [create_lidar(k, m) for m in poses]
+    rec, off = engine.scan_lidars(lidars, mesh, want=("t", "prim", "point3", "incident_deg"))
+    assert len(off) == 4 and off[0] == 0 and off[-1] == len(rec["t"]) and len(set(np.diff(off))) > 1
+    np.random.seed(11)
+    for i, m in enumerate(poses):
+        rays = create_lidar(k, m).get_rays()
+        assert len(rays) == off[i + 1] - off[i]
+
+        class Frozen:
+            intrinsics, pose = k, m
+            def get_rays(self):
+                return rays
+        ref_pts, ref_ang, ref_idx = np_oracle.lidar_intersect_mesh(om, Frozen(), threads=8, return_index=True)
+        sl = slice(off[i], off[i + 1])
+        keep = rec["t"][sl] != np.inf
+        assert np.array_equal(np.flatnonzero(keep), ref_idx)
+        assert_bit_equal(rec["point3"][sl][keep], ref_pts)
+        assert np.abs(rec["incident_deg"][sl][keep] - ref_ang).max() < 1e-9
+    scene = engine.scene_for(mesh)
+    with pytest.raises(ValueError):
+        scene.cast_segments(np.zeros((4, 6), np.float32), [0, 5], np.zeros((1, 3)), 1.0)     # offsets do not end at N
+    with pytest.raises(ValueError):
+        scene.cast_segments(np.zeros((4, 6), np.float32), [0, 3, 2, 4], np.zeros((3, 3)), 1.0)   # decreasing

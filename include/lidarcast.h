@@ -189,6 +189,28 @@ int lrc_compact(lrc_ctx* ctx, uint64_t num_segments, uint64_t seg_len,
 int lrc_compact_dev(lrc_ctx* ctx, uint64_t num_segments, uint64_t seg_len,
                     const lrc_compact_io* d_io, void* stream);
 
+/* ---- opt-in sensor-realism options --------------------------------
+ * The reference DECLARES these sensor parameters but never applies them (SURVEY.md F6, F7:
+ * Indoor8LineLidarIntrinsics.add_noise has no caller, lidar/lidar_intrinsics.py:364-389; min_range is never
+ * read by the engines; the "incident angle" ignores the surface, raycast_engine_cpu.py:100-107).  Everything
+ * is OFF by default, which is the reference's behaviour and what the parity tests pin.  Options are sticky
+ * on the scene handle until changed; pass NULL to reset.
+ *   min_range      > 0: a hit is kept only if its float64 distance from the centre is >= min_range
+ *   range_noise    additive noise in metres, one float per ray of the NEXT calls (drawn by the caller, e.g.
+ *                  from a seeded numpy stream, so that seeded runs are reproducible bit for bit):
+ *                  t' = t + noise (float32); t' <= 0 drops the return; point, range filter and incident
+ *                  angle use t'.  Host entry points take a host array, _dev entry points a device array;
+ *                  range_noise_len must equal the number of rays of the call.
+ *   incident_mode  0: reference (angle between centre->point and the vertical axis)
+ *                  1: angle between the ray and the hit triangle's normal, acos(|d^.n|) in degrees */
+typedef struct lrc_scan_options {
+    double       min_range;
+    const float* range_noise;
+    uint64_t     range_noise_len;
+    int          incident_mode;
+} lrc_scan_options;
+int lrc_scene_set_options(lrc_scene* scene, const lrc_scan_options* opts);
+
 /* Number of traversal-kernel launches and rays issued on this scene so far (bench bookkeeping). */
 int lrc_scene_get_counters(const lrc_scene* scene, uint64_t* launches, uint64_t* rays);
 

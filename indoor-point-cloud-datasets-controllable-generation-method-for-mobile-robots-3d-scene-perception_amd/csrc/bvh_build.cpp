@@ -54,7 +54,10 @@ struct TmpNode {
     int64_t child[2];   // >= 0: tmp inner index; < 0: leaf, ~child = first_slot*8 + count
 };
 
-constexpr int kBins = 16;
+#ifndef LRC_BINS
+#define LRC_BINS 64
+#endif
+constexpr int kBins = LRC_BINS;
 
 inline int ceil_log2_u64(uint64_t x) {   // smallest k with 2^k >= x  (x >= 1)
     int k = 0;

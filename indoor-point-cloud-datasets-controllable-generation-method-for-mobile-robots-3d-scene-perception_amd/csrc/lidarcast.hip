@@ -75,6 +75,7 @@ struct lrc_scene {
     uint32_t* d_slot_prim = nullptr;
     uint32_t* d_slot_label = nullptr;
     lrc_scene_info info{};
+    lrc_scan_options opts{};          // sticky opt-in options (lrc_scene_set_options)
     uint64_t launches = 0, rays = 0;
 };
 
@@ -101,6 +102,10 @@ struct TraceParams {
     int has_center;
     double cx, cy, cz;
     double max_range;
+    // opt-in sensor-realism options (lrc_scan_options; all off by default = the reference's behaviour)
+    double min_range;
+    const float* range_noise;
+    int incident_mode;
     lrc_hits out;
 };
 
@@ -276,6 +281,12 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
     float nx = 0.f, ny = 0.f, nz = 0.f, px = 0.f, py = 0.f, pz = 0.f;
     uint32_t label = 0;
     double inc = 0.0;
+    if (keep && p.range_noise) {
+        // opt-in range noise (the reference declares range_noise_std but never applies it, lidar_intrinsics.py:
+        // 364-389 has no caller): host-drawn additive noise on the range; a non-positive range drops the return
+        tbest = tbest + p.range_noise[gid];
+        keep = tbest > 0.0f;
+    }
     if (keep) {
         // p = o + (d/|d|)*t : numpy float32, one rounding per operation (raycast_engine_cpu.py:57-62)
         const float nrm = __builtin_sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z);
@@ -285,16 +296,26 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
         const double ex = (double)px - cx, ey = (double)py - cy, ez = (double)pz - cz;
         const double dist = __builtin_sqrt((ex * ex + ey * ey) + ez * ez);
         if (p.has_center || GEN) keep = dist < p.max_range;
+        if (p.min_range > 0.0) keep = keep & (dist >= p.min_range);     // opt-in; the reference never applies it
         if (keep) {
             t_out = tbest;
             prim = p.slot_prim[best_slot];
             label = p.slot_label[best_slot];
-            if (p.out.normal3) {
+            if (p.out.normal3 || (p.out.incident_deg && p.incident_mode == 1)) {
                 const float4 c = p.tris[(size_t)best_slot * 3 + 2];
                 const float len = __builtin_sqrtf(fma_(c.w, c.w, fma_(c.z, c.z, c.y * c.y)));
                 nx = c.y / len; ny = c.z / len; nz = c.w / len;
             }
-            if (p.out.incident_deg) inc = acos(__builtin_fabs(ez / dist)) * kRadToDeg;
+            if (p.out.incident_deg) {
+                if (p.incident_mode == 1) {   // opt-in: angle between the ray and the surface normal
+                    const double cs = __builtin_fabs(((double)hx * (double)nx + (double)hy * (double)ny) +
+                                                     (double)hz * (double)nz);
+                    inc = acos(cs < 1.0 ? cs : 1.0) * kRadToDeg;
+                } else {
+                    inc = acos(__builtin_fabs(ez / dist)) * kRadToDeg;
+                }
+            }
+            if (!p.out.normal3) { nx = ny = nz = 0.f; }
         } else {
             px = py = pz = 0.f;
         }
@@ -565,6 +586,15 @@ int lrc_scene_get_info(const lrc_scene* scene, lrc_scene_info* out_info) {
     return LRC_OK;
 }
 
+int lrc_scene_set_options(lrc_scene* scene, const lrc_scan_options* opts) {
+    if (!scene) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_set_options: scene is NULL");
+    if (!opts) { scene->opts = lrc_scan_options{}; return LRC_OK; }
+    if (!(opts->min_range >= 0.0) || (opts->incident_mode != 0 && opts->incident_mode != 1))
+        return fail(LRC_ERR_INVALID_ARG, "lrc_scene_set_options: min_range < 0 or unknown incident_mode");
+    scene->opts = *opts;
+    return LRC_OK;
+}
+
 int lrc_scene_get_counters(const lrc_scene* scene, uint64_t* launches, uint64_t* rays) {
     if (!scene) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_get_counters: scene is NULL");
     if (launches) *launches = scene->launches;
@@ -588,6 +618,13 @@ static int launch_trace(lrc_scene* s, TraceParams& p, bool gen, hipStream_t st) 
     p.slot_prim = s->d_slot_prim;
     p.slot_label = s->d_slot_label;
     p.num_nodes = (uint32_t)s->info.num_nodes;
+    p.min_range = s->opts.min_range;
+    p.incident_mode = s->opts.incident_mode;
+    if (!p.range_noise && s->opts.range_noise) {      // device entry points: the pointer is a device pointer
+        if (s->opts.range_noise_len != p.total)
+            return fail(LRC_ERR_INVALID_ARG, "range_noise_len does not match the number of rays of this call");
+        p.range_noise = s->opts.range_noise;
+    }
     if (p.total == 0) return LRC_OK;
     const uint64_t nblk = (p.total + kTBlock - 1) / kTBlock;
     if (nblk > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "too many rays for one launch");
@@ -704,6 +741,24 @@ struct HitsStage {
         return LRC_OK;
     }
 };
+// host entry points: lrc_scan_options.range_noise is a HOST array; stage it in HBM for the call
+struct NoiseStage {
+    lrc_scene* s = nullptr;
+    const float* host = nullptr;
+    DevBuf buf;
+    int begin(lrc_scene* scene, uint64_t n) {
+        if (!scene->opts.range_noise) return LRC_OK;
+        if (scene->opts.range_noise_len != n)
+            return fail(LRC_ERR_INVALID_ARG, "range_noise_len does not match the number of rays of this call");
+        LRC_HIP(hipMalloc(&buf.p, n * 4));
+        LRC_HIP(hipMemcpy(buf.p, scene->opts.range_noise, n * 4, hipMemcpyHostToDevice));
+        s = scene;
+        host = scene->opts.range_noise;
+        scene->opts.range_noise = (const float*)buf.p;
+        return LRC_OK;
+    }
+    ~NoiseStage() { if (s) s->opts.range_noise = host; }
+};
 }  // namespace
 
 int lrc_cast(lrc_scene* s, const float* rays6, uint64_t n, const double* center3, double max_range,
@@ -718,6 +773,8 @@ int lrc_cast(lrc_scene* s, const float* rays6, uint64_t n, const double* center3
     HitsStage st;
     int rc = st.alloc(*out, n);
     if (rc) return rc;
+    NoiseStage ns;
+    if ((rc = ns.begin(s, n))) return rc;
     rc = lrc_cast_dev(s, (const float*)rays.p, n, center3, max_range, &st.d, nullptr);
     if (rc) return rc;
     LRC_HIP(hipDeviceSynchronize());
@@ -746,6 +803,8 @@ int lrc_cast_segments(lrc_scene* s, const float* rays6, uint64_t n, const uint64
     HitsStage st;
     int rc = st.alloc(*out, n);
     if (rc) return rc;
+    NoiseStage ns;
+    if ((rc = ns.begin(s, n))) return rc;
     rc = lrc_cast_segments_dev(s, (const float*)rays.p, n, (const uint64_t*)offs.p, num_segments,
                                (const double*)cen.p, max_range, &st.d, nullptr);
     if (rc) return rc;
@@ -769,6 +828,8 @@ int lrc_scan_poses(lrc_scene* s, const double* poses16, uint64_t P, const double
     HitsStage st;
     int rc = st.alloc(*out, n);
     if (rc) return rc;
+    NoiseStage ns;
+    if ((rc = ns.begin(s, n))) return rc;
     rc = lrc_scan_poses_dev(s, (const double*)dp.p, P, (const double*)dd.p, N, max_range, &st.d, nullptr);
     if (rc) return rc;
     LRC_HIP(hipDeviceSynchronize());

@@ -24,7 +24,7 @@ SYMBOLS = (
     "lrc_version", "lrc_last_error", "lrc_device_count",
     "lrc_ctx_create", "lrc_ctx_destroy", "lrc_ctx_synchronize",
     "lrc_scene_create", "lrc_scene_destroy", "lrc_scene_get_info", "lrc_scene_export_bvh",
-    "lrc_scene_get_counters",
+    "lrc_scene_get_counters", "lrc_scene_set_options",
     "lrc_cast", "lrc_cast_dev", "lrc_cast_segments", "lrc_cast_segments_dev",
     "lrc_scan_poses", "lrc_scan_poses_dev",
     "lrc_compact", "lrc_compact_dev",
@@ -43,6 +43,11 @@ class LrcSceneInfo(C.Structure):
                 ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32),
                 ("device_bytes", C.c_uint64), ("build_ms", C.c_double), ("upload_ms", C.c_double),
                 ("bounds_lo", C.c_float * 3), ("bounds_hi", C.c_float * 3)]
+
+
+class LrcScanOptions(C.Structure):
+    _fields_ = [("min_range", C.c_double), ("range_noise", C.c_void_p), ("range_noise_len", C.c_uint64),
+                ("incident_mode", C.c_int)]
 
 
 class LrcCompactIO(C.Structure):
@@ -82,6 +87,7 @@ def load():
         "lrc_scene_get_info": [vp, C.POINTER(LrcSceneInfo)],
         "lrc_scene_export_bvh": [vp, vp, vp],
         "lrc_scene_get_counters": [vp, C.POINTER(u64), C.POINTER(u64)],
+        "lrc_scene_set_options": [vp, C.POINTER(LrcScanOptions)],
         "lrc_cast": [vp, vp, u64, vp, dbl, C.POINTER(LrcHits)],
         "lrc_cast_dev": [vp, vp, u64, vp, dbl, C.POINTER(LrcHits), vp],
         "lrc_cast_segments": [vp, vp, u64, vp, u64, vp, dbl, C.POINTER(LrcHits)],

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import LrcCompactIO, LrcHits, LrcSceneInfo, check
+from ._capi import LrcCompactIO, LrcHits, LrcScanOptions, LrcSceneInfo, check
 
 ATTRS = ("t", "prim", "normal3", "point3", "sem", "ins", "incident_deg")
 _NP_SPEC = {
@@ -176,6 +176,26 @@ class Scene:
         d["bounds_lo"] = tuple(inf.bounds_lo)
         d["bounds_hi"] = tuple(inf.bounds_hi)
         return d
+
+    def set_options(self, min_range=0.0, range_noise=None, incident_mode=0):
+        """Opt-in sensor-realism options (all off = the reference's behaviour); sticky until changed.
+        range_noise: float32 array, one entry per ray of the following host-array calls (kept alive here),
+        or a (data_ptr, length) pair of a device array for the device calls."""
+        o = LrcScanOptions()
+        o.min_range = float(min_range)
+        o.incident_mode = int(incident_mode)
+        self._noise_keepalive = None
+        if isinstance(range_noise, tuple):
+            o.range_noise, o.range_noise_len = int(range_noise[0]), int(range_noise[1])
+        elif range_noise is not None:
+            a = np.ascontiguousarray(range_noise, dtype=np.float32).reshape(-1)
+            self._noise_keepalive = a
+            o.range_noise, o.range_noise_len = a.ctypes.data, a.size
+        check(self._lib.lrc_scene_set_options(self._h, C.byref(o)), "lrc_scene_set_options")
+
+    def reset_options(self):
+        self._noise_keepalive = None
+        check(self._lib.lrc_scene_set_options(self._h, None), "lrc_scene_set_options")
 
     def counters(self):
         a, b = C.c_uint64(0), C.c_uint64(0)

@@ -515,3 +515,51 @@ def test_cast_segments_ragged_poses(engine, a1):
         scene.cast_segments(np.zeros((4, 6), np.float32), [0, 5], np.zeros((1, 3)), 1.0)     # offsets do not end at N
     with pytest.raises(ValueError):
         scene.cast_segments(np.zeros((4, 6), np.float32), [0, 3, 2, 4], np.zeros((3, 3)), 1.0)   # decreasing
+
+
+def test_opt_in_sensor_options(ctx):
+    """Row N4: min_range, host-drawn range noise and the ray/normal incident angle.  Off by default (the
+    reference never applies them); when on, checked against a numpy restatement."""
+    import lidarcast
+    from lidarcast import synth
+    from lidar import IndoorLidar, create_lidar
+    from oracle.c_oracle import OracleMesh
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=4, seed=5, cell=0.05)
+    scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles)
+    om = OracleMesh(mesh.vertices, mesh.triangles).build()
+    k = sensor_small(lines=6, width=300, max_range=2.6)
+    lidar = create_lidar(k, pose(1.4, 1.5, 1.0, 0.4))
+    rays = lidar.get_rays()
+    c = lidar.pose[:3, 3]
+    base = scene.cast(rays, center=c, max_range=k.max_range)
+    t0, prim0 = om.cast(rays)
+    rs = np.random.RandomState(5)
+    noise = rs.normal(0, 0.02, len(rays)).astype(np.float32)
+    noise[::50] = -100.0                                        # forces t' <= 0 on some rays
+    scene.set_options(min_range=0.9, range_noise=noise, incident_mode=1)
+    out = scene.cast(rays, center=c, max_range=k.max_range)
+    # numpy restatement
+    t1 = (t0 + noise).astype(np.float32)
+    ok = np.isfinite(t0) & (t1 > 0)
+    d = rays[:, 3:] / np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+    pts = np.where(ok[:, None], rays[:, :3] + d * np.where(ok, t1, 0)[:, None], 0).astype(np.float32)
+    dist = np.linalg.norm(pts.astype(np.float64) - c, axis=1)
+    keep = ok & (dist < k.max_range) & (dist >= 0.9)
+    assert 0 < keep.sum() < ok.sum() < len(rays)
+    assert np.array_equal(np.isfinite(out["t"]), keep)
+    assert_bit_equal(out["t"][keep], t1[keep])
+    assert_bit_equal(out["point3"][keep], pts[keep])
+    assert np.array_equal(out["prim"][keep], prim0[keep]) and (out["prim"][~keep] == 0xFFFFFFFF).all()
+    nrm = om.normals(prim0)[keep].astype(np.float64)
+    dd = d[keep].astype(np.float64)
+    cs = np.abs((dd[:, 0] * nrm[:, 0] + dd[:, 1] * nrm[:, 1]) + dd[:, 2] * nrm[:, 2])
+    want = np.degrees(np.arccos(np.minimum(cs, 1.0)))
+    assert np.abs(out["incident_deg"][keep] - want).max() < 1e-6 and out["incident_deg"][keep].max() <= 90.0
+    with pytest.raises(ValueError):
+        scene.cast(rays[:10], center=c, max_range=k.max_range)          # noise length mismatch
+    with pytest.raises(ValueError):
+        scene.set_options(min_range=-1.0)
+    scene.reset_options()
+    again = scene.cast(rays, center=c, max_range=k.max_range)
+    for key in ("t", "point3", "prim", "incident_deg"):
+        assert_bit_equal(again[key], base[key])

@@ -211,6 +211,21 @@ typedef struct lrc_scan_options {
 } lrc_scan_options;
 int lrc_scene_set_options(lrc_scene* scene, const lrc_scan_options* opts);
 
+/* ---- nearest annotated point --------------------------------------
+ * Exact 1-nearest-neighbour lookup of float32 query points in a float64 annotated cloud, float64 distances,
+ * ties to the smaller row.  Replaces sklearn NearestNeighbors(n_neighbors=1, algorithm='ball_tree')
+ * .fit(annotated).kneighbors(points) at containers/s3dis_sim_scene.py:416-418, which the reference runs on
+ * every frame's hit points at export time to attach colour / semantic / instance labels; also used once per
+ * mesh to bake per-triangle labels (triangle centroid -> nearest annotated point) that the trace kernel then
+ * writes back per ray.  cell_size <= 0 picks a grid spacing from the point density. */
+typedef struct lrc_nn lrc_nn;
+int lrc_nn_create(lrc_ctx* ctx, const double* points3, uint64_t num_points, double cell_size, lrc_nn** out_nn);
+int lrc_nn_destroy(lrc_nn* nn);
+int lrc_nn_query(lrc_nn* nn, const float* query3, uint64_t num_queries, uint32_t* out_index,
+                 double* out_dist /* nullable */);
+int lrc_nn_query_dev(lrc_nn* nn, const float* d_query3, uint64_t num_queries, uint32_t* d_out_index,
+                     double* d_out_dist /* nullable */, void* stream);
+
 /* Number of traversal-kernel launches and rays issued on this scene so far (bench bookkeeping). */
 int lrc_scene_get_counters(const lrc_scene* scene, uint64_t* launches, uint64_t* rays);
 

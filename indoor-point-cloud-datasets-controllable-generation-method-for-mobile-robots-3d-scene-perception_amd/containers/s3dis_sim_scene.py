@@ -76,6 +76,8 @@ class S3DISSimScene:
         self.statistics: Optional[SimulationStats] = None
         self.mesh = mesh
         self.s3dis_data_root, self.area, self.room = s3dis_data_root, area, room
+        self._annotated = None        # (points f64 (M,3), colors (M,3) in 0..1, sem (M,), ins (M,))
+        self._nn = None
 
     def append_frame(self, frame: S3DISSimFrame):
         self.frames.append(frame)
@@ -130,6 +132,33 @@ class S3DISSimScene:
             return np.empty(0, np.uint16), np.empty(0, np.uint16)
         return np.concatenate(sem).astype(np.uint16), np.concatenate(ins).astype(np.uint16)
 
+    # ---- export-time labels from an annotated cloud (the reference's semantics) -------------------------
+    def set_annotated_cloud(self, points, colors, semantic_labels, instance_labels):
+        """The arrays the reference reads from the S3DIS annotations and caches
+        (containers/s3dis_sim_scene.py:396-409).  Loading the annotation files is out of scope here."""
+        self._annotated = (np.ascontiguousarray(points, dtype=np.float64), np.asarray(colors),
+                           np.asarray(semantic_labels), np.asarray(instance_labels))
+        if self._nn is not None:
+            self._nn.close()
+        self._nn = None
+
+    def _get_default_colors_and_labels(self, num_points: int):
+        return (np.ones((num_points, 3), dtype=np.float32) * 0.5, np.zeros(num_points, dtype=np.uint16),
+                np.zeros(num_points, dtype=np.uint16))
+
+    def _get_colors_and_labels_from_s3dis(self, points: np.ndarray):
+        """Nearest annotated point per hit point -> (colors, semantic, instance); defaults without a cloud.
+        Same contract as the reference method of this name (:379-427); the ball-tree query is the GPU 1-NN."""
+        if self._annotated is None or len(points) == 0:
+            return self._get_default_colors_and_labels(len(points))
+        if self._nn is None:
+            import lidarcast
+            self._nn_ctx = lidarcast.Context(0)
+            self._nn = lidarcast.NearestIndex(self._nn_ctx, self._annotated[0])
+        idx = self._nn.query(points)
+        _, colors, sem, ins = self._annotated
+        return colors[idx], sem[idx], ins[idx]
+
     def save_results(self, output_dir, formats=("txt",)):
         out = Path(output_dir)
         out.mkdir(parents=True, exist_ok=True)
@@ -142,6 +171,15 @@ class S3DISSimScene:
         pts = self.combined_points()
         if len(pts) == 0:
             return
-        sem, ins = self.combined_labels()
-        colors = np.full((len(pts), 3), int(0.5 * 255), dtype=np.uint8)      # reference default grey
+        if self._annotated is not None:       # reference path: 1-NN into the annotated cloud, per frame (:347-356)
+            cols, sems, inss = [], [], []
+            for f in self.frames:
+                if len(f.points) > 0:
+                    c, s_, i_ = self._get_colors_and_labels_from_s3dis(f.points)
+                    cols.append(c); sems.append(s_); inss.append(i_)
+            colors = (np.vstack(cols) * 255).astype(np.uint8)
+            sem, ins = np.concatenate(sems).astype(np.uint16), np.concatenate(inss).astype(np.uint16)
+        else:                                 # labels written back by the trace kernel; reference default grey
+            sem, ins = self.combined_labels()
+            colors = np.full((len(pts), 3), int(0.5 * 255), dtype=np.uint8)
         write_labeled_ply(out / "combined_pointcloud_with_label.ply", pts, colors, sem, ins)

@@ -452,6 +452,10 @@ __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const lrc_compa
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
+// shared with the other translation units of the library (not part of the public ABI)
+int lrc_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
+int lrc_internal_ctx_device(const lrc_ctx* ctx) { return ctx ? ctx->device : 0; }
+
 const char* lrc_version(void) { return "lidarcast 0.1.0 (gfx950)"; }
 
 const char* lrc_last_error(void) { return g_err.c_str(); }

@@ -28,6 +28,7 @@ SYMBOLS = (
     "lrc_cast", "lrc_cast_dev", "lrc_cast_segments", "lrc_cast_segments_dev",
     "lrc_scan_poses", "lrc_scan_poses_dev",
     "lrc_compact", "lrc_compact_dev",
+    "lrc_nn_create", "lrc_nn_destroy", "lrc_nn_query", "lrc_nn_query_dev",
 )
 
 
@@ -94,6 +95,10 @@ def load():
         "lrc_cast_segments_dev": [vp, vp, u64, vp, u64, vp, dbl, C.POINTER(LrcHits), vp],
         "lrc_scan_poses": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcHits)],
         "lrc_scan_poses_dev": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcHits), vp],
+        "lrc_nn_create": [vp, vp, u64, dbl, C.POINTER(vp)],
+        "lrc_nn_destroy": [vp],
+        "lrc_nn_query": [vp, vp, u64, vp, vp],
+        "lrc_nn_query_dev": [vp, vp, u64, vp, vp, vp],
         "lrc_compact": [vp, u64, u64, C.POINTER(LrcCompactIO), C.POINTER(u64)],
         "lrc_compact_dev": [vp, u64, u64, C.POINTER(LrcCompactIO), vp],
     }

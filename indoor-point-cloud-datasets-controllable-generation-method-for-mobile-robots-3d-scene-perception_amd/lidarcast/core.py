@@ -272,3 +272,56 @@ class Scene:
                                            C.c_void_p(dirs_t.data_ptr()), N, float(max_range),
                                            C.byref(hits.struct), C.c_void_p(int(stream))),
               "lrc_scan_poses_dev")
+
+
+class NearestIndex:
+    """Exact 1-NN into an annotated cloud on the GPU (reference: sklearn ball_tree query,
+    containers/s3dis_sim_scene.py:416-418)."""
+
+    def __init__(self, ctx, points, cell_size=0.0):
+        self._lib = _capi.load()
+        self.ctx = ctx
+        p = np.ascontiguousarray(np.asarray(points), dtype=np.float64)
+        if p.ndim != 2 or p.shape[1] != 3 or len(p) == 0:
+            raise ValueError("points must be a non-empty (M, 3) array")
+        h = C.c_void_p()
+        check(self._lib.lrc_nn_create(ctx._h, _ptr(p), len(p), float(cell_size), C.byref(h)), "lrc_nn_create")
+        self._h = h
+        self.num_points = len(p)
+
+    def query(self, points, return_distance=False):
+        q = np.ascontiguousarray(np.asarray(points), dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != 3:
+            raise ValueError("query points must be (K, 3)")
+        idx = np.empty(len(q), dtype=np.uint32)
+        dist = np.empty(len(q), dtype=np.float64) if return_distance else None
+        check(self._lib.lrc_nn_query(self._h, _ptr(q), len(q), _ptr(idx), _ptr(dist)), "lrc_nn_query")
+        return (idx, dist) if return_distance else idx
+
+    def query_dev(self, q_t, idx_t, dist_t=None, stream=0):
+        check(self._lib.lrc_nn_query_dev(self._h, C.c_void_p(q_t.data_ptr()), q_t.shape[0],
+                                         C.c_void_p(idx_t.data_ptr()),
+                                         None if dist_t is None else C.c_void_p(dist_t.data_ptr()),
+                                         C.c_void_p(int(stream))), "lrc_nn_query_dev")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lrc_nn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bake_triangle_labels(index, vertices, triangles, semantic, instance):
+    """Per-triangle (sem, ins) from the annotated point nearest to each triangle centroid: labels are
+    attached once per mesh and written back by the trace kernel, instead of one 1-NN query per hit point at
+    export time (reference: containers/s3dis_sim_scene.py:339-377)."""
+    v = np.asarray(vertices, dtype=np.float64)
+    f = np.asarray(triangles)
+    cen = (v[f[:, 0]] + v[f[:, 1]] + v[f[:, 2]]) / 3.0
+    nearest = index.query(cen.astype(np.float32))
+    return (np.asarray(semantic)[nearest].astype(np.uint16), np.asarray(instance)[nearest].astype(np.uint16))

@@ -563,3 +563,86 @@ def test_opt_in_sensor_options(ctx):
     again = scene.cast(rays, center=c, max_range=k.max_range)
     for key in ("t", "point3", "prim", "incident_deg"):
         assert_bit_equal(again[key], base[key])
+
+
+def _surface_cloud(m, seed):
+    """annotated points on the faces of a 5 x 4 x 3 box with mm-level scatter (S3DIS-like density)"""
+    rng = np.random.default_rng(seed)
+    p = rng.uniform([0, 0, 0], [5, 4, 3], size=(m, 3))
+    face = rng.integers(0, 6, m)
+    for a in range(3):
+        p[face == 2 * a, a] = 0.0
+        p[face == 2 * a + 1, a] = [5, 4, 3][a]
+    return p + rng.normal(0, 0.002, p.shape)
+
+
+def test_nearest_annotated_point_vs_sklearn_ball_tree(ctx):
+    """Row N1: the GPU 1-NN against the reference's own query (sklearn ball_tree, s3dis_sim_scene.py:416-418)."""
+    import lidarcast
+    from sklearn.neighbors import NearestNeighbors
+    cloud = _surface_cloud(150_000, 1)
+    q = (_surface_cloud(40_000, 2) + np.random.default_rng(3).normal(0, 0.01, (40_000, 3))).astype(np.float32)
+    q[:50] += 3.0                                             # queries well outside the cloud's bounding box
+    nn = lidarcast.NearestIndex(ctx, cloud)
+    idx, dist = nn.query(q, return_distance=True)
+    ref_d, ref_i = NearestNeighbors(n_neighbors=1, algorithm="ball_tree").fit(cloud).kneighbors(q)
+    assert np.array_equal(idx, ref_i[:, 0].astype(np.uint32))
+    assert np.abs(dist - ref_d[:, 0]).max() < 1e-12
+    # brute force on a slice (float64, same expression)
+    sl = slice(0, 300)
+    d2 = ((q[sl].astype(np.float64)[:, None, :] - cloud[None, :, :]) ** 2)
+    d2 = (d2[..., 0] + d2[..., 1]) + d2[..., 2]
+    assert np.array_equal(idx[sl], d2.argmin(1).astype(np.uint32))
+    # other grid spacings give the same answer
+    for h in (0.01, 0.5, 50.0):
+        assert np.array_equal(lidarcast.NearestIndex(ctx, cloud, cell_size=h).query(q[:5000]), idx[:5000])
+    # duplicates: ties go to the smaller row; a single point; empty query
+    dup = np.concatenate([cloud[:1000], cloud[:1000]])
+    assert (lidarcast.NearestIndex(ctx, dup).query(cloud[:1000].astype(np.float32)) < 1000).all()
+    one = lidarcast.NearestIndex(ctx, np.array([[1.0, 2.0, 3.0]]))
+    assert (one.query(q[:100]) == 0).all() and one.query(np.zeros((0, 3), np.float32)).shape == (0,)
+    with pytest.raises(ValueError):
+        lidarcast.NearestIndex(ctx, np.zeros((0, 3)))
+
+
+def test_export_labels_from_annotated_cloud(tmp_path, engine):
+    """S3DISSimScene._get_colors_and_labels_from_s3dis with an annotated cloud == the reference's sklearn path;
+    baked per-triangle labels arrive per ray through the trace kernel."""
+    import lidarcast
+    from sklearn.neighbors import NearestNeighbors
+    from containers import S3DISSimFrame, S3DISSimScene, ScanQuality, read_labeled_ply
+    from lidarcast import synth
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=3, seed=8, cell=0.05)
+    rng = np.random.default_rng(0)
+    v = mesh.vertices
+    tri = mesh.triangles[rng.integers(0, len(mesh.triangles), 60_000)]
+    w = rng.dirichlet([1, 1, 1], len(tri))
+    ann = (v[tri] * w[:, :, None]).sum(1) + rng.normal(0, 0.003, (len(tri), 3))     # annotated cloud near the surfaces
+    ann_sem = rng.integers(0, 13, len(ann)).astype(np.uint16)
+    ann_ins = rng.integers(0, 300, len(ann)).astype(np.uint16)
+    ann_col = rng.random((len(ann), 3))
+    k = sensor_small(lines=8, width=256, max_range=20.0)
+    rec, n = engine.scan_poses(k, np.stack([pose(1.5, 1.5, 1.0), pose(2.5, 1.5, 1.0)]), mesh, want=("t", "point3"))
+    sc = S3DISSimScene("room")
+    sc.set_annotated_cloud(ann, ann_col, ann_sem, ann_ins)
+    q = ScanQuality(0, 0, 0, 0, 0, 0, 0)
+    for i in range(2):
+        pts = rec["point3"][i][np.isfinite(rec["t"][i])]
+        sc.append_frame(S3DISSimFrame(i, pts, np.zeros(len(pts)), q))
+    sc.save_results(tmp_path)
+    out = read_labeled_ply(tmp_path / "combined_pointcloud_with_label.ply")
+    allp = sc.combined_points()
+    ref_i = NearestNeighbors(n_neighbors=1, algorithm="ball_tree").fit(ann).kneighbors(allp)[1][:, 0]
+    assert np.array_equal(out["sem"], ann_sem[ref_i]) and np.array_equal(out["ins"], ann_ins[ref_i])
+    assert np.array_equal(np.stack([out["red"], out["green"], out["blue"]], 1), (ann_col[ref_i] * 255).astype(np.uint8))
+    # baking: labels per triangle once, then per ray from the kernel
+    nn = lidarcast.NearestIndex(engine.ctx, ann)
+    sem_t, ins_t = lidarcast.bake_triangle_labels(nn, mesh.vertices, mesh.triangles, ann_sem, ann_ins)
+    cen = mesh.vertices[mesh.triangles].mean(1)
+    ref_t = NearestNeighbors(n_neighbors=1, algorithm="ball_tree").fit(ann).kneighbors(cen.astype(np.float32))[1][:, 0]
+    assert np.array_equal(sem_t, ann_sem[ref_t]) and np.array_equal(ins_t, ann_ins[ref_t])
+    baked = synth.TriangleMesh(mesh.vertices, mesh.triangles, sem_t, ins_t)
+    rec2, _ = engine.scan_poses(k, np.stack([pose(1.5, 1.5, 1.0)]), baked, want=("t", "prim", "sem", "ins"))
+    hit = np.isfinite(rec2["t"][0])
+    assert np.array_equal(rec2["sem"][0][hit], sem_t[rec2["prim"][0][hit]])
+    assert np.array_equal(rec2["ins"][0][hit], ins_t[rec2["prim"][0][hit]])

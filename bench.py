@@ -160,51 +160,66 @@ def main():
     n = P * N
     d_poses = torch.from_numpy(poses.reshape(P, 16)).to(dev)
     d_dirs = torch.from_numpy(dirs).to(dev)
-    hits = lidarcast.DeviceHits(n, dev, want=("t", "prim", "normal3", "point3", "sem", "ins", "tile_count"))
-    # scene cloud: compacted 16-byte rows (x, y, z, sem|ins<<16) in np.vstack order + per-pose counts.
-    # N > 1: two send/receive buffer sets, so that the all-gather of scan i overlaps the trace of scan i+1.
     dist_path = world > 1 or args.dist_selftest
+    want = ("t", "prim", "normal3", "point3", "sem", "ins", "tile_count") + (("t_label",) if dist_path else ())
+    hits = lidarcast.DeviceHits(n, dev, want=want)
+    # scene cloud: compacted 16-byte rows (x, y, z, sem|ins<<16) in np.vstack order + per-pose counts.
+    cloud = torch.empty((n * world, 4), dtype=torch.float32, device=dev)
+    counts = torch.zeros(P * world, dtype=torch.int64, device=dev)
+    io = LrcCompactIO()
+    io.t, io.point3 = hits["t"].data_ptr(), hits["point3"].data_ptr()
+    io.sem, io.ins = hits["sem"].data_ptr(), hits["ins"].data_ptr()
+    io.tile_count = hits["tile_count"].data_ptr()
+    io.counts, io.out_xyzl = counts.data_ptr(), cloud.data_ptr()
+    stream = torch.cuda.current_stream().cuda_stream
     if dist_path:
-        from lidarcast.distributed import CloudGather
-        gathers = [CloudGather(n, P, dist, dev) for _ in range(2)]
-        bufs = [(g.slab, g.counts) for g in gathers]
+        # N > 1: every rank scans its own poses, ONE all-gather per scan moves the 8-byte (t, label) pairs
+        # (the trace kernel writes them straight into the send slab), and every rank rebuilds the whole cloud
+        # from the gathered pairs.  Two buffer sets: the collective of scan i overlaps the trace of scan i+1.
+        from lidarcast.distributed import RangeGather
+        gathers = [RangeGather(n, dist, dev) for _ in range(2)]
+        all_poses = np.concatenate([c3_poses(r, world) for r in range(world)]).reshape(P * world, 16)
+        d_all_poses = torch.from_numpy(all_poses).to(dev)
     else:
         gathers = None
-        bufs = [(torch.empty((n, 4), dtype=torch.float32, device=dev), torch.zeros(P, dtype=torch.int64, device=dev))]
-    ios = []
-    for cloud, cnt in bufs:
-        io = LrcCompactIO()
-        io.t, io.point3 = hits["t"].data_ptr(), hits["point3"].data_ptr()
-        io.sem, io.ins = hits["sem"].data_ptr(), hits["ins"].data_ptr()
-        io.tile_count = hits["tile_count"].data_ptr()
-        io.counts, io.out_xyzl = cnt.data_ptr(), cloud.data_ptr()
-        ios.append(io)
-    counts = bufs[0][1]
-    stream = torch.cuda.current_stream().cuda_stream
 
     k_events = []
-    state = {"i": 0}
+    state = {"i": 0, "pending": None}
+
+    def rebuild(g):
+        g.wait()                     # the compute stream waits for the collective
+        ctx.cloud_from_ranges_dev(d_all_poses, d_dirs, g.all_pairs, cloud, counts, stream)
 
     def step(timed):
-        i = state["i"] % len(ios)
-        state["i"] += 1
-        if gathers is not None:
-            gathers[i].wait()        # the collective that last used this buffer set must have finished
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        if gathers is None:
+            scene.scan_poses_dev(d_poses, d_dirs, hits, sensor.max_range, stream)
+            if timed:
+                e1.record()
+                k_events.append((e0, e1))
+            ctx.compact_dev(P, N, io, stream)
+            return
+        g = gathers[state["i"] % 2]
+        state["i"] += 1
+        hits.struct.t_label = g.slab.data_ptr()
         scene.scan_poses_dev(d_poses, d_dirs, hits, sensor.max_range, stream)
         if timed:
             e1.record()
             k_events.append((e0, e1))
-        ctx.compact_dev(P, N, ios[i], stream)
-        if gathers is not None:
-            gathers[i].gather(async_op=True)     # ONE RCCL all-gather per scan (rows + counts in one slab)
+        g.gather(async_op=True)
+        if state["pending"] is not None:
+            rebuild(state["pending"])            # cloud of the previous scan, while this scan's pairs travel
+        state["pending"] = g
+
+    def drain():
+        if gathers is not None and state["pending"] is not None:
+            rebuild(state["pending"])
+            state["pending"] = None
 
     def barrier():
-        if gathers is not None:
-            for g in gathers:
-                g.wait()
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -223,11 +238,16 @@ def main():
         elapsed = float(tmax.item())
 
     if args.dist_selftest:
-        pts, labs, cnts = gathers[0].assemble()
-        k = int(gathers[0].counts.sum().item())
-        assert pts.shape[0] == k * world and torch.equal(pts[:k], gathers[0].slab[:k, :3]), "gathered cloud differs"
-        assert torch.equal(cnts[:P], gathers[0].counts.cpu())
-        print(f"dist selftest ok: {k} rows gathered, world {world}", file=sys.stderr)
+        # the cloud rebuilt from the gathered pairs must equal the local compaction, bit for bit
+        k = int(counts.sum().item())
+        rebuilt = cloud[:k].clone()
+        rebuilt_counts = counts.clone()
+        ctx.compact_dev(P, N, io, stream)
+        torch.cuda.synchronize()
+        assert int(counts.sum().item()) == k and torch.equal(rebuilt_counts, counts), "per-pose counts differ"
+        assert torch.equal(rebuilt.view(torch.int32), cloud[:k].view(torch.int32)), "rebuilt cloud differs"
+        print(f"dist selftest ok: {k} rows rebuilt from gathered (t,label) pairs == local compaction, world {world}",
+              file=sys.stderr)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in k_events]))
     hits_total = int(counts.sum().item())
     total_rays = n * world * args.steps
@@ -246,12 +266,13 @@ def main():
                 "workload": f"C3: create_dense_32line x horizontal_res=2048 ({N} rays/pose) x {P} poses per GPU "
                             f"(straight line, yaw 0) over {args.scene} (procedural stand-in for an S3DIS "
                             f"Area_6 office mesh, 2 cm tessellation, T={info['num_triangles']})",
-                "rays_per_step_per_gpu": n, "hit_fraction": hits_total / n,
+                "rays_per_step_per_gpu": n, "hit_fraction": hits_total / (n * (world if dist_path else 1)),
                 "bvh": {"nodes": info["num_nodes"], "depth": info["max_depth"],
                         "build_ms": round(info["build_ms"], 1), "device_MB": round(info["device_bytes"] / 1e6, 1)},
-                "step": "in-kernel ray generation + BVH traversal + hit write-back (36 B/ray) + stable "
-                        "compaction into the scene cloud (16 B/hit)"
-                        + (" + one RCCL all-gather of the clouds" if world > 1 else ""),
+                "step": "in-kernel ray generation + BVH traversal + hit write-back (36 B/ray) + "
+                        + ("stable compaction into the scene cloud (16 B/hit)" if world == 1 else
+                           "one RCCL all-gather of the (t,label) pairs (8 B/ray) + rebuild of the whole scene "
+                           "cloud (16 B/hit, all ranks' poses) on every GPU"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

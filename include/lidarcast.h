@@ -59,6 +59,8 @@ typedef struct lrc_hits {
     uint16_t* ins;           /* (n)    instance label of the hit triangle; 0 on miss                 */
     double*   incident_deg;  /* (n)    degrees(arccos(|((p-c)/|p-c|)_z|)) in float64
                                        (raycast_engine_cpu.py:100-107); 0 on miss                    */
+    void*     t_label;       /* (n) x 8 B  DEVICE entry points only: packed {float t; uint32 sem|ins<<16}, the
+                                       pair lrc_cloud_from_ranges_dev needs to rebuild a hit point          */
     uint32_t* tile_count;    /* (ceil(n/64)) DEVICE entry points only: number of kept entries in each
                                        aligned run of 64 outputs; lets lrc_compact_dev skip its counting
                                        pass (lrc_compact_io.tile_count).  Ignored by the host entry points */
@@ -210,6 +212,18 @@ typedef struct lrc_scan_options {
     int          incident_mode;
 } lrc_scan_options;
 int lrc_scene_set_options(lrc_scene* scene, const lrc_scan_options* opts);
+
+/* ---- scene cloud from per-ray (t, label) pairs of a pose-batched scan ------------------------------
+ * A pose-batched scan is a pure function of (poses16, dirs3): whoever holds those can rebuild the hit point of
+ * ray (p,i) from its t alone, with the same float32 arithmetic as the scan itself (bit-identical rows).  The
+ * multi-GPU assembly therefore all-gathers 8-byte (t, label) pairs (lrc_hits.t_label) instead of 16-byte rows
+ * and every rank runs this function over the gathered pairs of all poses:
+ *   d_t_label : (P*N) x {float t; uint32 label}, +inf = no return
+ *   d_out_xyzl: (K,4) rows x, y, z, label bits, stable pose-major order (np.vstack of the frames,
+ *               containers/s3dis_sim_scene.py:326); d_counts (P), nullable: kept rays per pose. */
+int lrc_cloud_from_ranges_dev(lrc_ctx* ctx, const double* d_poses16, uint64_t num_poses,
+                              const double* d_dirs3, uint64_t rays_per_pose, const void* d_t_label,
+                              float* d_out_xyzl, uint64_t* d_counts, void* stream);
 
 /* ---- nearest annotated point --------------------------------------
  * Exact 1-nearest-neighbour lookup of float32 query points in a float64 annotated cloud, float64 distances,

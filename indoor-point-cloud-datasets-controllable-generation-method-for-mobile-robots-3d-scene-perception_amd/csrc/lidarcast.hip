@@ -137,15 +137,7 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
     if (GEN) {
         const uint64_t pose = gid / p.rays_per_pose;
         const uint64_t i = gid - pose * p.rays_per_pose;
-        const double* M = p.poses16 + pose * 16;
-        const double* dv = p.dirs3 + i * 3;
-        const double a = dv[0], b = dv[1], c = dv[2];
-        // rays_d = np.dot(directions, R.T) in float64, then .astype(float32)  (indoor_lidar.py:127-131)
-        d.x = (float)((a * M[0] + b * M[1]) + c * M[2]);
-        d.y = (float)((a * M[4] + b * M[5]) + c * M[6]);
-        d.z = (float)((a * M[8] + b * M[9]) + c * M[10]);
-        cx = M[3]; cy = M[7]; cz = M[11];
-        o.x = (float)cx; o.y = (float)cy; o.z = (float)cz;
+        gen_ray(p.poses16, p.dirs3, pose, i, o, d, cx, cy, cz);
     } else {
         const float* r = p.rays6 + gid * 6;
         o.x = r[0]; o.y = r[1]; o.z = r[2];
@@ -289,9 +281,10 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
     }
     if (keep) {
         // p = o + (d/|d|)*t : numpy float32, one rounding per operation (raycast_engine_cpu.py:57-62)
-        const float nrm = __builtin_sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z);
-        const float hx = d.x / nrm, hy = d.y / nrm, hz = d.z / nrm;
-        px = o.x + hx * tbest; py = o.y + hy * tbest; pz = o.z + hz * tbest;
+        V3 hh, pp;
+        hit_point(o, d, tbest, hh, pp);
+        const float hx = hh.x, hy = hh.y, hz = hh.z;
+        px = pp.x; py = pp.y; pz = pp.z;
         // range filter + incident angle in float64 (raycast_engine_cpu.py:95-107)
         const double ex = (double)px - cx, ey = (double)py - cy, ez = (double)pz - cz;
         const double dist = __builtin_sqrt((ex * ex + ey * ey) + ez * ez);
@@ -325,6 +318,7 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
         if ((tid & 63u) == 0) p.out.tile_count[gid >> 6] = (uint32_t)__popcll(m);
     }
     if (p.out.t) p.out.t[gid] = t_out;
+    if (p.out.t_label) ((uint2*)p.out.t_label)[gid] = make_uint2(__float_as_uint(t_out), label);
     if (p.out.prim) p.out.prim[gid] = prim;
     if (STATS) { nx = st_nodes; ny = st_tris; nz = st_uni + st_dead / 1024.0f; }   // nz = uniform + dead/1024
     if (p.out.normal3) { float* q = p.out.normal3 + gid * 3; q[0] = nx; q[1] = ny; q[2] = nz; }
@@ -443,6 +437,57 @@ __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const lrc_compa
     if (io.out_ins) io.out_ins[dst] = io.ins[src];
     if (io.out_incident_deg) io.out_incident_deg[dst] = io.incident_deg[src];
     if (io.out_index) io.out_index[dst] = (uint32_t)i;
+}
+
+// ---- scene cloud from per-ray (t, label) pairs -------------------------------------------------------
+// A pose-batched scan is a pure function of (pose, direction table), so a rank that holds the poses and the
+// table can rebuild any other rank's hit points from the 8-byte pair alone: this is what the multi-GPU
+// all-gather moves instead of 16-byte rows.  Same arithmetic as the trace epilogue (gen_ray + hit_point).
+
+__global__ __launch_bounds__(kBlock) void cloud_count_kernel(const uint2* tl, uint64_t seg_len, uint64_t tps,
+                                                             uint64_t ntiles, uint32_t* tile_cnt) {
+    const uint64_t tile = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const uint64_t seg = tile / tps, chunk = tile - seg * tps;
+    const uint64_t i = chunk * 64 + (threadIdx.x & 63u);
+    bool keep = false;
+    if (i < seg_len) keep = __uint_as_float(tl[seg * seg_len + i].x) < __builtin_inff();
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63u) == 0) tile_cnt[tile] = (uint32_t)__popcll(m);
+}
+
+__global__ __launch_bounds__(kBlock) void cloud_scatter_kernel(const double* poses16, const double* dirs3,
+                                                               const uint2* tl, uint64_t seg_len, uint64_t tps,
+                                                               uint64_t ntiles, uint64_t nseg,
+                                                               const uint32_t* tile_off, const uint64_t* super_base,
+                                                               float4* out_xyzl, uint64_t* counts) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (counts) {
+        const uint64_t sg = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (sg < nseg) {
+            const uint64_t nsuper = (ntiles + 1023) / 1024;
+            const uint64_t g0 = sg * tps, g1 = g0 + tps;
+            const uint64_t o0 = g0 >= ntiles ? super_base[nsuper] : super_base[g0 >> 10] + tile_off[g0];
+            const uint64_t o1 = g1 >= ntiles ? super_base[nsuper] : super_base[g1 >> 10] + tile_off[g1];
+            counts[sg] = o1 - o0;
+        }
+    }
+    const uint64_t tile = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const uint64_t seg = tile / tps, chunk = tile - seg * tps;
+    const uint64_t i = chunk * 64 + lane;
+    uint2 rec = make_uint2(0x7F800000u, 0u);
+    if (i < seg_len) rec = tl[seg * seg_len + i];
+    const float t = __uint_as_float(rec.x);
+    const bool keep = t < __builtin_inff();
+    const unsigned long long m = __ballot(keep);
+    if (!keep) return;
+    const uint64_t dst = super_base[tile >> 10] + tile_off[tile] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+    V3 o, d, h, pt;
+    double cx, cy, cz;
+    gen_ray(poses16, dirs3, seg, i, o, d, cx, cy, cz);
+    hit_point(o, d, t, h, pt);
+    out_xyzl[dst] = make_float4(pt.x, pt.y, pt.z, __uint_as_float(rec.y));
 }
 
 }  // namespace
@@ -840,6 +885,8 @@ int lrc_scan_poses(lrc_scene* s, const double* poses16, uint64_t P, const double
     return st.download(*out, n);
 }
 
+static int ensure_tile_scratch(lrc_ctx* ctx, uint64_t ntiles);
+
 int lrc_compact_dev(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_compact_io* io,
                     void* stream) {
     if (!ctx || !io) return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: NULL argument");
@@ -854,17 +901,9 @@ int lrc_compact_dev(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_com
     const uint64_t ntiles = nseg * tps;
     const uint64_t nblocks = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
     if (nblocks > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: too many entries");
-    if (ctx->tile_cap < ntiles + 1) {
-        if (ctx->d_tile_off) { (void)hipFree(ctx->d_tile_off); ctx->d_tile_off = nullptr; }
-        if (ctx->d_tile_cnt) { (void)hipFree(ctx->d_tile_cnt); ctx->d_tile_cnt = nullptr; }
-        if (ctx->d_super_total) { (void)hipFree(ctx->d_super_total); ctx->d_super_total = nullptr; }
-        if (ctx->d_super_base) { (void)hipFree(ctx->d_super_base); ctx->d_super_base = nullptr; }
-        ctx->tile_cap = 0;
-        LRC_HIP(hipMalloc((void**)&ctx->d_tile_off, (ntiles + 1) * 4));
-        LRC_HIP(hipMalloc((void**)&ctx->d_tile_cnt, (ntiles + 1) * 4));
-        LRC_HIP(hipMalloc((void**)&ctx->d_super_total, ((ntiles + 1023) / 1024 + 1) * 4));
-        LRC_HIP(hipMalloc((void**)&ctx->d_super_base, ((ntiles + 1023) / 1024 + 1) * 8));
-        ctx->tile_cap = ntiles + 1;
+    {
+        int rc_scratch = ensure_tile_scratch(ctx, ntiles);
+        if (rc_scratch) return rc_scratch;
     }
     // the trace kernel can hand over its per-wave keep counts (lrc_hits.tile_count) when tiles line up
     const uint32_t* cnt = (io->tile_count && seg_len % 64 == 0) ? io->tile_count : nullptr;
@@ -883,6 +922,51 @@ int lrc_compact_dev(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_com
     const uint64_t grid = nblocks > need ? nblocks : need;
     hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, st, *io, seg_len, tps,
                        ntiles, nseg, (const uint32_t*)ctx->d_tile_off, (const uint64_t*)ctx->d_super_base);
+    LRC_HIP(hipGetLastError());
+    return LRC_OK;
+}
+
+static int ensure_tile_scratch(lrc_ctx* ctx, uint64_t ntiles) {
+    if (ctx->tile_cap >= ntiles + 1) return LRC_OK;
+    if (ctx->d_tile_off) { (void)hipFree(ctx->d_tile_off); ctx->d_tile_off = nullptr; }
+    if (ctx->d_tile_cnt) { (void)hipFree(ctx->d_tile_cnt); ctx->d_tile_cnt = nullptr; }
+    if (ctx->d_super_total) { (void)hipFree(ctx->d_super_total); ctx->d_super_total = nullptr; }
+    if (ctx->d_super_base) { (void)hipFree(ctx->d_super_base); ctx->d_super_base = nullptr; }
+    ctx->tile_cap = 0;
+    LRC_HIP(hipMalloc((void**)&ctx->d_tile_off, (ntiles + 1) * 4));
+    LRC_HIP(hipMalloc((void**)&ctx->d_tile_cnt, (ntiles + 1) * 4));
+    LRC_HIP(hipMalloc((void**)&ctx->d_super_total, ((ntiles + 1023) / 1024 + 1) * 4));
+    LRC_HIP(hipMalloc((void**)&ctx->d_super_base, ((ntiles + 1023) / 1024 + 1) * 8));
+    ctx->tile_cap = ntiles + 1;
+    return LRC_OK;
+}
+
+int lrc_cloud_from_ranges_dev(lrc_ctx* ctx, const double* d_poses16, uint64_t P, const double* d_dirs3,
+                              uint64_t N, const void* d_t_label, float* d_out_xyzl, uint64_t* d_counts,
+                              void* stream) {
+    if (!ctx) return fail(LRC_ERR_INVALID_ARG, "lrc_cloud_from_ranges_dev: ctx is NULL");
+    if (P == 0 || N == 0) return LRC_OK;
+    if (!d_poses16 || !d_dirs3 || !d_t_label || !d_out_xyzl)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_cloud_from_ranges_dev: NULL argument");
+    LRC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t tps = (N + 63) / 64, ntiles = P * tps;
+    const uint64_t nblocks = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+    if (nblocks > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "lrc_cloud_from_ranges_dev: too many entries");
+    int rc = ensure_tile_scratch(ctx, ntiles);
+    if (rc) return rc;
+    const uint64_t nsuper = (ntiles + 1023) / 1024;
+    hipLaunchKernelGGL(cloud_count_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, (const uint2*)d_t_label, N,
+                       tps, ntiles, ctx->d_tile_cnt);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(1024), 0, st,
+                       (const uint32_t*)ctx->d_tile_cnt, ctx->d_tile_off, ntiles, ctx->d_super_total);
+    hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)ctx->d_super_total,
+                       ctx->d_super_base, nsuper);
+    const uint64_t need = d_counts ? (P + kBlock - 1) / kBlock : 0;
+    const uint64_t grid = nblocks > need ? nblocks : need;
+    hipLaunchKernelGGL(cloud_scatter_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, st, d_poses16, d_dirs3,
+                       (const uint2*)d_t_label, N, tps, ntiles, P, (const uint32_t*)ctx->d_tile_off,
+                       (const uint64_t*)ctx->d_super_base, (float4*)d_out_xyzl, d_counts);
     LRC_HIP(hipGetLastError());
     return LRC_OK;
 }

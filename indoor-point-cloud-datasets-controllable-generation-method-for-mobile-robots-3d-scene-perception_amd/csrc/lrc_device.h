@@ -99,4 +99,26 @@ LRC_DI bool tri_hit(V3 o, V3 d, const RaySlab& s, V3 v0, V3 v1, V3 v2, V3 ng, fl
     return true;
 }
 
+// Ray (pose, i) of a pose-batched scan: origin = float32(pose[:3,3]); direction = float32(dirs3[i] @ R^T)
+// evaluated in float64 left to right (reference: lidar/indoor_lidar.py:127-131).  c = pose[:3,3] in float64.
+LRC_DI void gen_ray(const double* poses16, const double* dirs3, uint64_t pose, uint64_t i, V3& o, V3& d,
+                    double& cx, double& cy, double& cz) {
+    const double* M = poses16 + pose * 16;
+    const double* dv = dirs3 + i * 3;
+    const double a = dv[0], b = dv[1], c = dv[2];
+    d.x = (float)((a * M[0] + b * M[1]) + c * M[2]);
+    d.y = (float)((a * M[4] + b * M[5]) + c * M[6]);
+    d.z = (float)((a * M[8] + b * M[9]) + c * M[10]);
+    cx = M[3]; cy = M[7]; cz = M[11];
+    o.x = (float)cx; o.y = (float)cy; o.z = (float)cz;
+}
+
+// p = o + (d/|d|)*t : numpy float32, one rounding per operation (reference: raycast_engine_cpu.py:57-62).
+// h receives the normalised direction.
+LRC_DI void hit_point(V3 o, V3 d, float t, V3& h, V3& pt) {
+    const float nrm = __builtin_sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z);
+    h.x = d.x / nrm; h.y = d.y / nrm; h.z = d.z / nrm;
+    pt.x = o.x + h.x * t; pt.y = o.y + h.y * t; pt.z = o.z + h.z * t;
+}
+
 }  // namespace lrcdev

@@ -27,7 +27,7 @@ SYMBOLS = (
     "lrc_scene_get_counters", "lrc_scene_set_options",
     "lrc_cast", "lrc_cast_dev", "lrc_cast_segments", "lrc_cast_segments_dev",
     "lrc_scan_poses", "lrc_scan_poses_dev",
-    "lrc_compact", "lrc_compact_dev",
+    "lrc_compact", "lrc_compact_dev", "lrc_cloud_from_ranges_dev",
     "lrc_nn_create", "lrc_nn_destroy", "lrc_nn_query", "lrc_nn_query_dev",
 )
 
@@ -35,7 +35,7 @@ SYMBOLS = (
 class LrcHits(C.Structure):
     _fields_ = [("t", C.c_void_p), ("prim", C.c_void_p), ("normal3", C.c_void_p),
                 ("point3", C.c_void_p), ("sem", C.c_void_p), ("ins", C.c_void_p),
-                ("incident_deg", C.c_void_p), ("tile_count", C.c_void_p)]
+                ("incident_deg", C.c_void_p), ("t_label", C.c_void_p), ("tile_count", C.c_void_p)]
 
 
 class LrcSceneInfo(C.Structure):
@@ -99,6 +99,7 @@ def load():
         "lrc_nn_destroy": [vp],
         "lrc_nn_query": [vp, vp, u64, vp, vp],
         "lrc_nn_query_dev": [vp, vp, u64, vp, vp, vp],
+        "lrc_cloud_from_ranges_dev": [vp, vp, u64, vp, u64, vp, vp, vp, vp],
         "lrc_compact": [vp, u64, u64, C.POINTER(LrcCompactIO), C.POINTER(u64)],
         "lrc_compact_dev": [vp, u64, u64, C.POINTER(LrcCompactIO), vp],
     }

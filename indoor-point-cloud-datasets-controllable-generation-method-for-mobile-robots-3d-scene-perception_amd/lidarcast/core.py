@@ -95,6 +95,14 @@ class Context:
             res[name] = o[:k]
         return res
 
+    def cloud_from_ranges_dev(self, poses_t, dirs_t, t_label_t, out_rows_t, counts_t=None, stream=0):
+        """Rebuild the compacted (x, y, z, label) rows of a pose-batched scan from its (t, label) pairs."""
+        check(self._lib.lrc_cloud_from_ranges_dev(
+            self._h, C.c_void_p(poses_t.data_ptr()), poses_t.shape[0], C.c_void_p(dirs_t.data_ptr()),
+            dirs_t.shape[0], C.c_void_p(t_label_t.data_ptr()), C.c_void_p(out_rows_t.data_ptr()),
+            None if counts_t is None else C.c_void_p(counts_t.data_ptr()), C.c_void_p(int(stream))),
+            "lrc_cloud_from_ranges_dev")
+
     def compact_dev(self, nseg, seg_len, io, stream=0):
         """io: LrcCompactIO filled with device pointers."""
         check(self._lib.lrc_compact_dev(self._h, int(nseg), int(seg_len), C.byref(io),
@@ -105,7 +113,8 @@ class DeviceHits:
     """Fixed-stride per-ray records in HBM (torch tensors), n entries."""
 
     _TORCH = {"t": "float32", "prim": "int32", "normal3": "float32", "point3": "float32",
-              "sem": "int16", "ins": "int16", "incident_deg": "float64", "tile_count": "int32"}
+              "sem": "int16", "ins": "int16", "incident_deg": "float64", "tile_count": "int32",
+              "t_label": "int32"}
 
     def __init__(self, n, device, want=("t", "prim", "normal3", "point3", "sem", "ins")):
         import torch
@@ -116,6 +125,8 @@ class DeviceHits:
             shape = (self.n, 3) if a.endswith("3") else (self.n,)
             if a == "tile_count":          # kept rays per aligned run of 64 outputs (feeds compact_dev)
                 shape = ((self.n + 63) // 64,)
+            if a == "t_label":             # packed {float t, uint32 label}: what the multi-GPU gather moves
+                shape = (self.n, 2)
             self.tensors[a] = torch.empty(shape, dtype=getattr(torch, self._TORCH[a]), device=device)
         self.struct = LrcHits()
         for a in self.want:
@@ -126,7 +137,7 @@ class DeviceHits:
 
     def bytes_per_ray(self):
         return sum(t.element_size() * (3 if a.endswith("3") else 1) for a, t in self.tensors.items()
-                   if a != "tile_count")
+                   if a not in ("tile_count", "t_label"))
 
 
 class Scene:

@@ -66,6 +66,32 @@ class CloudGather:
         return torch.cat(pts), torch.cat(labs), torch.cat(counts)
 
 
+class RangeGather:
+    """The all-gather the pose-batched scan uses: 8-byte (t, label) pairs instead of 16-byte rows.
+
+    A pose-batched scan is a pure function of (poses, direction table), which every rank holds, so a hit
+    point can be rebuilt anywhere from its t (lrc_cloud_from_ranges_dev, bit-identical to the scan's own
+    point).  ``slab`` (n, 2) int32 is the rank's send buffer -- the trace kernel writes its pairs straight
+    into it (lrc_hits.t_label) -- and ``all_pairs`` (world*n, 2) receives every rank's pairs in rank order,
+    i.e. in global pose order because ranks own contiguous pose blocks.  One collective per scan; halves the
+    bytes on the xGMI links, which is what bounds the multi-GPU job."""
+
+    def __init__(self, n_local, dist, device):
+        import torch
+        self.dist, self.world, self.n = dist, dist.get_world_size(), int(n_local)
+        self.slab = torch.empty((self.n, 2), dtype=torch.int32, device=device)
+        self.all_pairs = torch.empty((self.world * self.n, 2), dtype=torch.int32, device=device)
+        self.work = None
+
+    def gather(self, async_op=False):
+        self.work = self.dist.all_gather_into_tensor(self.all_pairs, self.slab, async_op=async_op)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+
 def gather_cloud(local_points, local_labels, local_counts, max_local, dist, device=None):
     """One-shot convenience form: all-gather a rank's compacted cloud given as separate tensors.
     Returns (points (K,3), labels (K,), per_pose_counts (P,)) assembled in rank -> pose -> ray order."""

@@ -25,7 +25,7 @@ def test_header_and_library_agree():
 def test_struct_layouts_match_header():
     import ctypes as C
     from lidarcast._capi import LrcCompactIO, LrcHits, LrcSceneInfo
-    assert C.sizeof(LrcHits) == 8 * 8
+    assert C.sizeof(LrcHits) == 9 * 8
     assert C.sizeof(LrcCompactIO) == 13 * 8
     assert C.sizeof(LrcSceneInfo) == 5 * 8 + 2 * 4 + 8 + 2 * 8 + 6 * 4
 

@@ -95,3 +95,74 @@ def test_shard_bounds():
     assert shard_bounds(7, 3).tolist() == [0, 3, 5, 7]
     assert shard_bounds(2, 4).tolist() == [0, 1, 2, 2, 2]
     assert shard_bounds(0, 2).tolist() == [0, 0, 0]
+
+
+def _pairs_worker(rank, world, port, q):
+    """RangeGather protocol over gloo: each rank contributes fixed-stride (t, label) pairs of its pose block;
+    rebuilding points from the gathered pairs (numpy stand-in for lrc_cloud_from_ranges_dev, the real kernel is
+    checked against the local compaction in the -m gpu tests) gives the vstack cloud on every rank."""
+    for p in (PKG, REPO, os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from lidarcast.distributed import RangeGather, shard_bounds
+    from lidar import create_lidar
+    from lidarcast import synth
+    from oracle.c_oracle import OracleMesh
+    from helpers import sensor_small
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    poses = _all_poses(6)                      # 6 poses: equal blocks for world 2 and 3
+    b = shard_bounds(len(poses), world)
+    mesh = synth.make_room(size=(3, 2.5, 2), num_boxes=2, seed=4, cell=0.1)
+    om = OracleMesh(mesh.vertices, mesh.triangles).build()
+    k = sensor_small(lines=3, width=40, max_range=1.6)
+    n_per = 120
+    mine = poses[b[rank]:b[rank + 1]]
+    g = RangeGather(len(mine) * n_per, dist, torch.device("cpu"))
+    pairs = np.zeros((len(mine) * n_per, 2), np.int32)
+    for j, m in enumerate(mine):
+        lidar = create_lidar(k, m)
+        rays = lidar.get_rays()
+        t, prim = om.cast(rays)
+        d = rays[:, 3:] / np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+        pts = rays[:, :3] + d * np.where(np.isfinite(t), t, 0)[:, None]
+        keep = np.isfinite(t) & (np.linalg.norm(pts.astype(np.float64) - m[:3, 3], axis=1) < k.max_range)
+        t = np.where(keep, t, np.inf).astype(np.float32)
+        lab = np.where(keep, mesh.triangle_sem[np.minimum(prim, len(mesh.triangles) - 1)].astype(np.uint32) |
+                       (mesh.triangle_ins[np.minimum(prim, len(mesh.triangles) - 1)].astype(np.uint32) << 16), 0)
+        pairs[j * n_per:(j + 1) * n_per, 0] = t.view(np.int32)
+        pairs[j * n_per:(j + 1) * n_per, 1] = lab.astype(np.uint32).view(np.int32)
+    g.slab.copy_(torch.from_numpy(pairs))
+    g.gather(async_op=True)
+    g.wait()
+    allp = g.all_pairs.numpy()
+    # rebuild: same formulas as the scan (o + d/|d| * t, float32), global pose order = rank order
+    rows = []
+    for gp, m in enumerate(poses):
+        rays = create_lidar(k, m).get_rays()
+        t = allp[gp * n_per:(gp + 1) * n_per, 0].copy().view(np.float32)
+        keep = np.isfinite(t)
+        d = rays[:, 3:] / np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+        rows.append((rays[:, :3] + d * np.where(keep, t, 0)[:, None])[keep])
+    cloud = np.concatenate(rows).astype(np.float32)
+    q.put((rank, hashlib.sha256(cloud.tobytes()).hexdigest(), len(cloud)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pair_gather_rebuilds_the_vstack_cloud(world):
+    pts, _, _, _ = _scan_block(_all_poses(6))
+    want = hashlib.sha256(pts.tobytes()).hexdigest()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pairs_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, h, k in got:
+        assert k == len(pts) and h == want, f"rank {rank} rebuilt a different cloud"

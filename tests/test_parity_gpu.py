@@ -374,7 +374,7 @@ def test_device_path_fused_tile_counts_and_packed_rows(ctx):
         P, N = len(poses), len(dirs)
         ref = scene.scan_poses(poses, dirs, k.max_range, want=("t", "point3", "sem", "ins"))
         dev = torch.device("cuda", 0)
-        hits = lidarcast.DeviceHits(P * N, dev, want=("t", "point3", "sem", "ins", "tile_count"))
+        hits = lidarcast.DeviceHits(P * N, dev, want=("t", "point3", "sem", "ins", "tile_count", "t_label"))
         d_poses = torch.from_numpy(poses.reshape(P, 16)).to(dev)
         d_dirs = torch.from_numpy(dirs).to(dev)
         rows = torch.zeros((P * N, 4), dtype=torch.float32, device=dev)
@@ -393,6 +393,15 @@ def test_device_path_fused_tile_counts_and_packed_rows(ctx):
         assert_bit_equal(got[:, :3], ref["point3"][keep])
         lab = ref["sem"][keep].astype(np.uint32) | (ref["ins"][keep].astype(np.uint32) << 16)
         assert np.array_equal(got[:, 3].copy().view(np.uint32), lab)
+        # the same rows rebuilt from the 8-byte (t, label) pairs alone (what the multi-GPU all-gather moves)
+        rows2 = torch.zeros_like(rows)
+        counts2 = torch.zeros_like(counts)
+        ctx.cloud_from_ranges_dev(d_poses, d_dirs, hits["t_label"], rows2, counts2, st)
+        torch.cuda.synchronize()
+        assert torch.equal(counts2, counts)
+        assert torch.equal(rows2[:keep.sum()].view(torch.int32), rows[:keep.sum()].view(torch.int32))
+        tl = hits["t_label"].cpu().numpy()
+        assert np.array_equal(tl[:, 0].copy().view(np.float32), ref["t"])
         tc = hits["tile_count"].cpu().numpy()
         pad = np.zeros(len(tc) * 64, bool)
         pad[:P * N] = keep

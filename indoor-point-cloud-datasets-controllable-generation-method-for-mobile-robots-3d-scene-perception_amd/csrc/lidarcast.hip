@@ -58,8 +58,15 @@ constexpr int kStack = LRC_MAX_BVH_DEPTH;
 
 }  // namespace
 
+enum PoolSlot { kPoolRays = 0, kPoolT, kPoolPrim, kPoolNormal, kPoolPoint, kPoolSem, kPoolIns, kPoolInc,
+                kPoolPoses, kPoolDirs, kPoolOffs, kPoolCen, kPoolNoise, kPoolSlots };
+
 struct lrc_ctx {
     int device = 0;
+    // staging buffers of the host-pointer entry points, grown on demand and reused (a per-waypoint caller
+    // such as the reference loop, s3dis_simulator.py:254-264, would otherwise pay hipMalloc/hipFree per pose)
+    void* pool[kPoolSlots] = {};
+    size_t pool_cap[kPoolSlots] = {};
     // compaction scratch (grown on demand, reused): per-tile counts and exclusive offsets
     uint32_t* d_tile_off = nullptr;     // offset of a tile inside its super tile (1024 tiles)
     uint32_t* d_tile_cnt = nullptr;
@@ -529,6 +536,8 @@ int lrc_ctx_create(int device, lrc_ctx** out_ctx) {
 int lrc_ctx_destroy(lrc_ctx* ctx) {
     if (!ctx) return LRC_OK;
     (void)hipSetDevice(ctx->device);
+    for (int k = 0; k < kPoolSlots; ++k)
+        if (ctx->pool[k]) (void)hipFree(ctx->pool[k]);
     if (ctx->d_tile_off) (void)hipFree(ctx->d_tile_off);
     if (ctx->d_tile_cnt) (void)hipFree(ctx->d_tile_cnt);
     if (ctx->d_super_total) (void)hipFree(ctx->d_super_total);
@@ -762,20 +771,34 @@ int lrc_scan_poses_dev(lrc_scene* s, const double* d_poses16, uint64_t P, const 
 namespace {
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool pooled = false;
+    ~DevBuf() { if (p && !pooled) (void)hipFree(p); }
+    // buffer of the context's staging pool (kept for the next call)
+    int get(lrc_ctx* ctx, int slot, size_t bytes) {
+        if (ctx->pool_cap[slot] < bytes) {
+            if (ctx->pool[slot]) { (void)hipFree(ctx->pool[slot]); ctx->pool[slot] = nullptr; ctx->pool_cap[slot] = 0; }
+            const size_t cap = bytes + bytes / 8;
+            LRC_HIP(hipMalloc(&ctx->pool[slot], cap));
+            ctx->pool_cap[slot] = cap;
+        }
+        p = ctx->pool[slot];
+        pooled = true;
+        return LRC_OK;
+    }
 };
 struct HitsStage {
     DevBuf t, prim, normal3, point3, sem, ins, inc;
     lrc_hits d{};
-    int alloc(const lrc_hits& h, uint64_t n) {
+    int alloc(lrc_ctx* ctx, const lrc_hits& h, uint64_t n) {
         if (!n) return LRC_OK;
-        if (h.t) { LRC_HIP(hipMalloc(&t.p, n * 4)); d.t = (float*)t.p; }
-        if (h.prim) { LRC_HIP(hipMalloc(&prim.p, n * 4)); d.prim = (uint32_t*)prim.p; }
-        if (h.normal3) { LRC_HIP(hipMalloc(&normal3.p, n * 12)); d.normal3 = (float*)normal3.p; }
-        if (h.point3) { LRC_HIP(hipMalloc(&point3.p, n * 12)); d.point3 = (float*)point3.p; }
-        if (h.sem) { LRC_HIP(hipMalloc(&sem.p, n * 2)); d.sem = (uint16_t*)sem.p; }
-        if (h.ins) { LRC_HIP(hipMalloc(&ins.p, n * 2)); d.ins = (uint16_t*)ins.p; }
-        if (h.incident_deg) { LRC_HIP(hipMalloc(&inc.p, n * 8)); d.incident_deg = (double*)inc.p; }
+        int rc;
+        if (h.t) { if ((rc = t.get(ctx, kPoolT, n * 4))) return rc; d.t = (float*)t.p; }
+        if (h.prim) { if ((rc = prim.get(ctx, kPoolPrim, n * 4))) return rc; d.prim = (uint32_t*)prim.p; }
+        if (h.normal3) { if ((rc = normal3.get(ctx, kPoolNormal, n * 12))) return rc; d.normal3 = (float*)normal3.p; }
+        if (h.point3) { if ((rc = point3.get(ctx, kPoolPoint, n * 12))) return rc; d.point3 = (float*)point3.p; }
+        if (h.sem) { if ((rc = sem.get(ctx, kPoolSem, n * 2))) return rc; d.sem = (uint16_t*)sem.p; }
+        if (h.ins) { if ((rc = ins.get(ctx, kPoolIns, n * 2))) return rc; d.ins = (uint16_t*)ins.p; }
+        if (h.incident_deg) { if ((rc = inc.get(ctx, kPoolInc, n * 8))) return rc; d.incident_deg = (double*)inc.p; }
         return LRC_OK;
     }
     int download(const lrc_hits& h, uint64_t n) {
@@ -799,7 +822,8 @@ struct NoiseStage {
         if (!scene->opts.range_noise) return LRC_OK;
         if (scene->opts.range_noise_len != n)
             return fail(LRC_ERR_INVALID_ARG, "range_noise_len does not match the number of rays of this call");
-        LRC_HIP(hipMalloc(&buf.p, n * 4));
+        int rc = buf.get(scene->ctx, kPoolNoise, n * 4);
+        if (rc) return rc;
         LRC_HIP(hipMemcpy(buf.p, scene->opts.range_noise, n * 4, hipMemcpyHostToDevice));
         s = scene;
         host = scene->opts.range_noise;
@@ -817,11 +841,11 @@ int lrc_cast(lrc_scene* s, const float* rays6, uint64_t n, const double* center3
     if (!n) return LRC_OK;
     LRC_HIP(hipSetDevice(s->ctx->device));
     DevBuf rays;
-    LRC_HIP(hipMalloc(&rays.p, n * 24));
+    int rc = rays.get(s->ctx, kPoolRays, n * 24);
+    if (rc) return rc;
     LRC_HIP(hipMemcpy(rays.p, rays6, n * 24, hipMemcpyHostToDevice));
     HitsStage st;
-    int rc = st.alloc(*out, n);
-    if (rc) return rc;
+    if ((rc = st.alloc(s->ctx, *out, n))) return rc;
     NoiseStage ns;
     if ((rc = ns.begin(s, n))) return rc;
     rc = lrc_cast_dev(s, (const float*)rays.p, n, center3, max_range, &st.d, nullptr);
@@ -843,15 +867,15 @@ int lrc_cast_segments(lrc_scene* s, const float* rays6, uint64_t n, const uint64
             return fail(LRC_ERR_INVALID_ARG, "lrc_cast_segments: offsets must be non-decreasing");
     LRC_HIP(hipSetDevice(s->ctx->device));
     DevBuf rays, offs, cen;
-    LRC_HIP(hipMalloc(&rays.p, n * 24));
-    LRC_HIP(hipMalloc(&offs.p, (num_segments + 1) * 8));
-    LRC_HIP(hipMalloc(&cen.p, num_segments * 24));
+    int rc;
+    if ((rc = rays.get(s->ctx, kPoolRays, n * 24)) || (rc = offs.get(s->ctx, kPoolOffs, (num_segments + 1) * 8)) ||
+        (rc = cen.get(s->ctx, kPoolCen, num_segments * 24)))
+        return rc;
     LRC_HIP(hipMemcpy(rays.p, rays6, n * 24, hipMemcpyHostToDevice));
     LRC_HIP(hipMemcpy(offs.p, seg_offsets, (num_segments + 1) * 8, hipMemcpyHostToDevice));
     LRC_HIP(hipMemcpy(cen.p, centers3, num_segments * 24, hipMemcpyHostToDevice));
     HitsStage st;
-    int rc = st.alloc(*out, n);
-    if (rc) return rc;
+    if ((rc = st.alloc(s->ctx, *out, n))) return rc;
     NoiseStage ns;
     if ((rc = ns.begin(s, n))) return rc;
     rc = lrc_cast_segments_dev(s, (const float*)rays.p, n, (const uint64_t*)offs.p, num_segments,
@@ -870,13 +894,12 @@ int lrc_scan_poses(lrc_scene* s, const double* poses16, uint64_t P, const double
     if (!n) return LRC_OK;
     LRC_HIP(hipSetDevice(s->ctx->device));
     DevBuf dp, dd;
-    LRC_HIP(hipMalloc(&dp.p, P * 128));
-    LRC_HIP(hipMalloc(&dd.p, N * 24));
+    int rc;
+    if ((rc = dp.get(s->ctx, kPoolPoses, P * 128)) || (rc = dd.get(s->ctx, kPoolDirs, N * 24))) return rc;
     LRC_HIP(hipMemcpy(dp.p, poses16, P * 128, hipMemcpyHostToDevice));
     LRC_HIP(hipMemcpy(dd.p, dirs3, N * 24, hipMemcpyHostToDevice));
     HitsStage st;
-    int rc = st.alloc(*out, n);
-    if (rc) return rc;
+    if ((rc = st.alloc(s->ctx, *out, n))) return rc;
     NoiseStage ns;
     if ((rc = ns.begin(s, n))) return rc;
     rc = lrc_scan_poses_dev(s, (const double*)dp.p, P, (const double*)dd.p, N, max_range, &st.d, nullptr);

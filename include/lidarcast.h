@@ -240,6 +240,16 @@ int lrc_nn_query(lrc_nn* nn, const float* query3, uint64_t num_queries, uint32_t
 int lrc_nn_query_dev(lrc_nn* nn, const float* d_query3, uint64_t num_queries, uint32_t* d_out_index,
                      double* d_out_dist /* nullable */, void* stream);
 
+/* ---- validation metrics ---------------------------------------------
+ * The O(n*m) parts of the reference's sampled cloud metrics (evaluate_single_scene.py:55-111), host arrays:
+ *   lrc_min_distances : out_min[i] = min_j |a_i - b_j| in float32 (sum of squares, one sqrt): the directed
+ *                       term of compute_chamfer_distance (:81-96) and compute_hausdorff_distance (:98-111)
+ *   lrc_rbf_kernel_sum: sum_ij exp(-gamma * max(|a_i|^2 + |b_j|^2 - 2 a_i.b_j, 0)), float64: one of the
+ *                       three kernel sums of compute_mmd_sampled (:55-79) */
+int lrc_min_distances(lrc_ctx* ctx, const float* a3, uint64_t n, const float* b3, uint64_t m, float* out_min);
+int lrc_rbf_kernel_sum(lrc_ctx* ctx, const float* a3, uint64_t n, const float* b3, uint64_t m, double gamma,
+                       double* out_sum);
+
 /* Number of traversal-kernel launches and rays issued on this scene so far (bench bookkeeping). */
 int lrc_scene_get_counters(const lrc_scene* scene, uint64_t* launches, uint64_t* rays);
 

@@ -655,3 +655,22 @@ def test_export_labels_from_annotated_cloud(tmp_path, engine):
     hit = np.isfinite(rec2["t"][0])
     assert np.array_equal(rec2["sem"][0][hit], sem_t[rec2["prim"][0][hit]])
     assert np.array_equal(rec2["ins"][0][hit], ins_t[rec2["prim"][0][hit]])
+
+
+def test_kernel_variants_are_bit_identical():
+    """Traversal order / fetch strategy / leaf size must not change a single output byte:
+    the scalar-fetch, leaf-pair, speculative-postponement and small-leaf variants against the default."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    tool = os.path.join(REPO, "tools", "variant_digest.py")
+    digests = {}
+    for name, env in {"default": {}, "no_scalar_fetch": {"LRC_UNIFORM": "0"}, "leaf_pairs": {"LRC_LEAFW": "2"},
+                      "speculative": {"LRC_SPEC": "1"}, "leaves_of_2": {"LRC_MAX_LEAF": "2"},
+                      "leaves_of_1": {"LRC_MAX_LEAF": "1"}}.items():
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=300, env=e, check=True)
+        digests[name] = r.stdout.strip().splitlines()[-1]
+    assert len(set(digests.values())) == 1, digests
+    assert int(digests["default"].split()[1]) > 30000 and int(digests["default"].split()[2]) > 1000

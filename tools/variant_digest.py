@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Print a SHA-256 over the hit records of a fixed small scan.  Run under different LRC_* kernel variants
+(LRC_UNIFORM, LRC_LEAFW, LRC_SPEC, LRC_MAX_LEAF): the digest must not change (tests/test_parity_gpu.py)."""
+import hashlib
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402,F401
+import numpy as np  # noqa: E402
+import lidarcast  # noqa: E402
+from lidar import Indoor8LineLidarIntrinsics, IndoorLidar  # noqa: E402
+from lidarcast import synth  # noqa: E402
+
+mesh = synth.make_room(size=(4.0, 3.0, 2.5), num_boxes=4, seed=5, cell=0.04)
+ctx = lidarcast.Context(0)
+scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
+k = Indoor8LineLidarIntrinsics(vertical_res=8, horizontal_res=1024, max_range=20.0,
+                               vertical_degrees=[25.0, 15.0, 5.0, 0.0, -5.0, -15.0, -25.0, -35.0])
+poses = np.stack([np.eye(4) for _ in range(4)])
+poses[:, :3, 3] = [(0.8, 1.2, 1.0), (1.6, 1.4, 1.0), (2.4, 1.6, 1.1), (3.2, 1.5, 0.9)]
+out = scene.scan_poses(poses, IndoorLidar(k, np.eye(4)).sensor_directions(), k.max_range)
+rng = np.random.default_rng(1)
+soup = rng.uniform(-3, 3, (3000, 1, 3)) + rng.normal(scale=0.4, size=(3000, 3, 3))
+scene2 = lidarcast.Scene(ctx, soup.reshape(-1, 3), np.arange(9000).reshape(-1, 3))
+o = rng.uniform(-3, 3, (20000, 3))
+d = rng.normal(size=(20000, 3))
+out2 = scene2.cast(np.concatenate([o, d], 1).astype(np.float32))
+h = hashlib.sha256()
+for res in (out, out2):
+    for key in ("t", "prim", "normal3", "point3", "sem", "ins", "incident_deg"):
+        h.update(res[key].tobytes())
+print(h.hexdigest(), int(np.isfinite(out["t"]).sum()), int(np.isfinite(out2["t"]).sum()))

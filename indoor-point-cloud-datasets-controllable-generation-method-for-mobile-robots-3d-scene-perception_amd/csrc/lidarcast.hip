@@ -6,11 +6,13 @@
 // and, for pose batches, the per-waypoint loop body of s3dis_simulator.py:254-264.
 //
 // Kernels
-//   trace_kernel<GEN>   one lane per ray; while-while BVH2 traversal with the per-lane stack in LDS
-//                       ([depth][lane], conflict free), fused hit write-back (t, prim, normal, point,
-//                       labels, range filter, incident angle).  GEN = rays generated from
-//                       (pose, direction table) inside the kernel.
-//   compact_*           stable stream compaction of the fixed-stride records into frame order.
+//   trace_kernel<GEN,..> one lane per ray, one wave per workgroup; while-while BVH2 traversal with the per-lane
+//                        stack in LDS ([depth][lane], conflict free); wave-uniform nodes fetched through the
+//                        scalar cache (s_load); fused hit write-back (t, prim, normal, point, labels, range
+//                        filter, incident angle, packed (t,label) pair, per-wave keep count).
+//                        GEN = rays generated from (pose, direction table) inside the kernel.
+//   compact_*            stable stream compaction of the fixed-stride records into frame order.
+//   cloud_*              the same compaction with the hit point rebuilt from (t, label) pairs (multi-GPU assembly).
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -54,7 +56,6 @@ constexpr int kBlock = 256;          // compaction kernels
 #define LRC_TRACE_BLOCK 64
 #endif
 constexpr int kTBlock = LRC_TRACE_BLOCK;   // trace kernel workgroup (rays per tile)
-constexpr int kStack = LRC_MAX_BVH_DEPTH;
 
 }  // namespace
 
@@ -119,6 +120,9 @@ struct TraceParams {
 // workgroup -> tile remap: consecutive tiles land on the same XCD (blocks b, b+8, ... share an L2),
 // so each XCD's 4 MiB L2 keeps the part of the scene its run of poses/scanlines looks at.
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nwg) {
+#ifdef LRC_NO_XCD_REMAP
+    return b;      // A/B build only
+#endif
     uint32_t q = nwg >> 3, r = nwg & 7u, x = b & 7u;
     uint32_t base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + (b >> 3);
@@ -592,6 +596,7 @@ int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32
     lrc::HostBVH h;
     lrc::BuildOptions opt;
     if (const char* e = std::getenv("LRC_MAX_LEAF")) opt.max_leaf = std::atoi(e);
+    if (const char* e = std::getenv("LRC_BFS_NODES")) opt.bfs_nodes = std::atoi(e);
     auto t0 = std::chrono::steady_clock::now();
     try {
         lrc::build_bvh(verts3, V, tris3, T, tri_sem, tri_ins, opt, &h);

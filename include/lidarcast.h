@@ -149,8 +149,9 @@ int lrc_cast_segments_dev(lrc_scene* scene, const float* d_rays6, uint64_t num_r
  *          trajectory/trajectory_generator.py:30-44).
  * dirs3  : (N,3) float64 sensor-frame unit directions, line-major/azimuth-minor
  *          (IndoorLidar._gen_lidar_rays_with_vertical_degrees, lidar/indoor_lidar.py:108-126).
- * Ray (p,i): origin = float32(pose[:3,3]); direction = float32(dirs3[i] @ R^T) evaluated in
- * float64 left to right (lidar/indoor_lidar.py:127-131); then exactly lrc_cast with
+ * Ray (p,i): origin = float32(pose[:3,3]); direction = float32(dirs3[i] @ R^T) evaluated in float64 as the
+ * fused chain fma(c,R[j][2], fma(b,R[j][1], a*R[j][0])) -- what numpy's BLAS product gives bit for bit
+ * (lidar/indoor_lidar.py:127-131); then exactly lrc_cast with
  * center = pose[:3,3] and max_range.  Output index = p*N + i.
  * Replaces the per-waypoint loop body s3dis_simulator.py:254-264. */
 int lrc_scan_poses(lrc_scene* scene, const double* poses16, uint64_t num_poses,

@@ -99,16 +99,20 @@ LRC_DI bool tri_hit(V3 o, V3 d, const RaySlab& s, V3 v0, V3 v1, V3 v2, V3 ng, fl
     return true;
 }
 
-// Ray (pose, i) of a pose-batched scan: origin = float32(pose[:3,3]); direction = float32(dirs3[i] @ R^T)
-// evaluated in float64 left to right (reference: lidar/indoor_lidar.py:127-131).  c = pose[:3,3] in float64.
+// Ray (pose, i) of a pose-batched scan: origin = float32(pose[:3,3]); direction = float32(dirs3[i] @ R^T).
+// The reference forms the product with np.dot(directions, pose[:3,:3].T) in float64 (lidar/indoor_lidar.py:127-131),
+// i.e. BLAS dgemm, whose kernels accumulate over k with fused multiply-adds: out_j = fma(c, R[j][2],
+// fma(b, R[j][1], a*R[j][0])).  Reproduced here term for term, so the float64 product -- and hence the float32
+// direction -- is bit-identical for rotated poses too (checked against vectors captured from the reference at
+// yaw 0.7, tests/golden/).  c = pose[:3,3] in float64.
 LRC_DI void gen_ray(const double* poses16, const double* dirs3, uint64_t pose, uint64_t i, V3& o, V3& d,
                     double& cx, double& cy, double& cz) {
     const double* M = poses16 + pose * 16;
     const double* dv = dirs3 + i * 3;
     const double a = dv[0], b = dv[1], c = dv[2];
-    d.x = (float)((a * M[0] + b * M[1]) + c * M[2]);
-    d.y = (float)((a * M[4] + b * M[5]) + c * M[6]);
-    d.z = (float)((a * M[8] + b * M[9]) + c * M[10]);
+    d.x = (float)__builtin_fma(c, M[2], __builtin_fma(b, M[1], a * M[0]));
+    d.y = (float)__builtin_fma(c, M[6], __builtin_fma(b, M[5], a * M[4]));
+    d.z = (float)__builtin_fma(c, M[10], __builtin_fma(b, M[9], a * M[8]));
     cx = M[3]; cy = M[7]; cz = M[11];
     o.x = (float)cx; o.y = (float)cy; o.z = (float)cz;
 }

@@ -63,10 +63,10 @@ class IndoorLidar:
         return out.reshape(H * W, 3).astype(np.float32)
 
     def sensor_directions(self):
-        """float64 (N,3) table for the in-kernel generator, or None when the branch is not supported there."""
+        """float64 (N,3) pose-independent direction table for the in-kernel generator."""
         k = self.intrinsics
-        if k.vertical_degrees is None:
-            return None
+        if k.vertical_degrees is None:      # the reference narrows this branch's table to float32 before rotating
+            return self.directions_uniform(k.fov_up, k.fov_down, k.vertical_res, k.horizontal_res).astype(np.float64)
         return self.directions_from_vertical_degrees(k.vertical_degrees, k.horizontal_res)
 
     # -- world-frame rays ---------------------------------------------------------------------------

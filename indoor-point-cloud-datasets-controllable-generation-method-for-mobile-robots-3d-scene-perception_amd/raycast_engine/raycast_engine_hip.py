@@ -49,6 +49,7 @@ class RaycastEngineHIP(RaycastEngineBase):
         self.verbose = verbose
         self.ctx = Context(device)          # raises when there is no GPU / no library
         self._scenes = {}                   # id(mesh) -> (weakref or None, fingerprint, Scene)
+        self._dir_tables = {}
         self._max_cached = int(max_cached_scenes)
 
     # ---- scene cache: build once per mesh ---------------------------------------------------------
@@ -105,12 +106,39 @@ class RaycastEngineHIP(RaycastEngineBase):
         out = scene.cast(rays.astype(np.float32), want=("t", "point3"))
         return out["point3"][out["t"] != np.inf]
 
+    def _direction_table(self, intrinsics):
+        """Pose-independent float64 direction table of a multi-line sensor, cached per (elevations, width)."""
+        from lidar import IndoorLidar
+        k = intrinsics
+        if k.vertical_degrees is None:      # uniform-elevation branch: the reference narrows the table to float32 first
+            key = ("uniform", float(k.fov_up), float(k.fov_down), int(k.vertical_res), int(k.horizontal_res))
+        else:
+            key = (tuple(k.vertical_degrees), int(k.horizontal_res))
+        tab = self._dir_tables.get(key)
+        if tab is None:
+            if k.vertical_degrees is None:
+                tab = IndoorLidar.directions_uniform(k.fov_up, k.fov_down, k.vertical_res,
+                                                     k.horizontal_res).astype(np.float64)
+            else:
+                tab = IndoorLidar.directions_from_vertical_degrees(k.vertical_degrees, k.horizontal_res)
+            if len(self._dir_tables) >= 8:
+                self._dir_tables.pop(next(iter(self._dir_tables)))
+            self._dir_tables[key] = tab
+        return tab
+
     def lidar_intersect_mesh(self, lidar, mesh):
-        rays = lidar.get_rays()
-        self._check_rays(rays)
+        from lidar import IndoorLidar
         scene = self.scene_for(mesh)
-        out = scene.cast(rays.astype(np.float32), center=np.asarray(lidar.pose)[:3, 3],
-                         max_range=lidar.intrinsics.max_range, want=("t", "point3", "incident_deg"))
+        if type(lidar) is IndoorLidar and (lidar.intrinsics.vertical_degrees is None or len(lidar.intrinsics.vertical_degrees)):
+            # this package's own multi-line sensor: rays are generated in the kernel from the direction table
+            # (bit-identical to lidar.get_rays(), rotated poses included) instead of on the host
+            out = scene.scan_poses(np.asarray(lidar.pose, dtype=np.float64)[None], self._direction_table(lidar.intrinsics),
+                                   lidar.intrinsics.max_range, want=("t", "point3", "incident_deg"))
+        else:
+            rays = lidar.get_rays()
+            self._check_rays(rays)
+            out = scene.cast(rays.astype(np.float32), center=np.asarray(lidar.pose)[:3, 3],
+                             max_range=lidar.intrinsics.max_range, want=("t", "point3", "incident_deg"))
         keep = out["t"] != np.inf
         points = out["point3"][keep]
         if len(points) > 0:
@@ -126,9 +154,9 @@ class RaycastEngineHIP(RaycastEngineBase):
         """
         from lidar import IndoorLidar
         poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 4, 4)
-        dirs = IndoorLidar(intrinsics=intrinsics, pose=np.eye(4)).sensor_directions()
-        if dirs is None:
+        if not hasattr(intrinsics, "horizontal_res") or hasattr(intrinsics, "swing_amplitude"):
             raise ValueError("sensor has no pose-independent direction table")
+        dirs = self._direction_table(intrinsics)
         scene = self.scene_for(mesh)
         out = scene.scan_poses(poses, dirs, intrinsics.max_range, want=want)
         P, N = poses.shape[0], dirs.shape[0]

@@ -104,7 +104,20 @@ def test_sensor_direction_table_is_the_pose_free_part(golden):
     R = arrays["pose_translated"][:3, :3]
     world = ((dirs[:, 0:1] * R[:, 0] + dirs[:, 1:2] * R[:, 1]) + dirs[:, 2:3] * R[:, 2]).astype(np.float32)
     assert_bit_equal(world, arrays["g1_8x512_translated"][:, 3:])
-    assert IndoorLidar(dataclasses.replace(k, vertical_degrees=None), np.eye(4)).sensor_directions() is None
+    # rotated pose: the reference's np.dot is a BLAS product = fused chain fma(c,R2, fma(b,R1, a*R0)); the scan
+    # kernel evaluates exactly that chain.  Emulated here with exact rational arithmetic on a sample.
+    from fractions import Fraction
+    R = arrays["pose_yawed"][:3, :3]
+    ref = arrays["g1_8x512_yawed"][:, 3:]
+    for i in range(0, len(dirs), 41):
+        for j in range(3):
+            inner = float(Fraction(dirs[i, 0]) * Fraction(R[j, 0]))
+            inner = float(Fraction(dirs[i, 1]) * Fraction(R[j, 1]) + Fraction(inner))
+            val = float(Fraction(dirs[i, 2]) * Fraction(R[j, 2]) + Fraction(inner))
+            assert np.float32(val) == ref[i, j]
+            assert val == float(np.dot(dirs[i:i + 1], R.T)[0, j])
+    u = IndoorLidar(dataclasses.replace(k, vertical_degrees=None), np.eye(4)).sensor_directions()
+    assert u.dtype == np.float64 and np.array_equal(u.astype(np.float32), arrays["g2_uniform_8x512_identity"][:, 3:])
 
 
 def test_g5_waypoint_pose(golden):

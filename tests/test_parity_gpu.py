@@ -268,15 +268,34 @@ def test_scan_poses_matches_per_pose_calls(engine):
         lidar = create_lidar(k, poses[p])
         ref_pts, ref_ang, ref_idx = np_oracle.lidar_intersect_mesh(om, lidar, threads=4, return_index=True)
         keep = rec["t"][p] != np.inf
-        if p < 5:      # yaw = 0: in-kernel ray generation is bit-identical to the host generator
-            assert np.array_equal(np.flatnonzero(keep), ref_idx)
-            assert_bit_equal(rec["point3"][p][keep], ref_pts)
-            assert np.abs(rec["incident_deg"][p][keep] - ref_ang).max() < 1e-9
-        else:          # rotated: directions may differ by 1 ulp (BLAS vs in-kernel float64 order)
-            assert abs(int(keep.sum()) - len(ref_idx)) <= 2
-            common = np.intersect1d(np.flatnonzero(keep), ref_idx)
-            sel = np.isin(ref_idx, common)
-            assert np.abs(rec["point3"][p][common] - ref_pts[sel]).max() < 1e-4
+        # in-kernel ray generation is bit-identical to the host generator (numpy + BLAS), rotated pose included
+        assert np.array_equal(np.flatnonzero(keep), ref_idx)
+        assert_bit_equal(rec["point3"][p][keep], ref_pts)
+        assert np.abs(rec["incident_deg"][p][keep] - ref_ang).max() < 1e-9
+
+
+def test_uniform_fov_branch_and_drop_in_fast_path(engine):
+    """lidar_intersect_mesh on this package's IndoorLidar (rays generated in the kernel) == the same call through a
+    duck-typed lidar that forces host get_rays(), for both ray-generator branches and a rotated pose."""
+    import dataclasses
+    from lidar import create_lidar
+    from lidarcast import synth
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=4, seed=5, cell=0.05)
+    for k in (sensor_small(lines=5, width=160, max_range=2.4),
+              dataclasses.replace(sensor_small(lines=6, width=128, max_range=20.0), vertical_degrees=None,
+                                  fov_up=20.0, fov_down=30.0)):
+        for m in (pose(1.2, 1.4, 1.0), pose(2.2, 1.6, 1.1, yaw=-2.3)):
+            lidar = create_lidar(k, m)
+
+            class Duck:
+                intrinsics, pose = lidar.intrinsics, lidar.pose
+                def get_rays(self):
+                    return lidar.get_rays()
+            fast_pts, fast_ang = engine.lidar_intersect_mesh(lidar, mesh)
+            host_pts, host_ang = engine.lidar_intersect_mesh(Duck(), mesh)
+            assert len(host_pts) > 100
+            assert_bit_equal(fast_pts, host_pts)
+            assert_bit_equal(fast_ang, host_ang)
 
 
 def test_compaction_matches_numpy(ctx):

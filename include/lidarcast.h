@@ -251,6 +251,16 @@ int lrc_min_distances(lrc_ctx* ctx, const float* a3, uint64_t n, const float* b3
 int lrc_rbf_kernel_sum(lrc_ctx* ctx, const float* a3, uint64_t n, const float* b3, uint64_t m, double gamma,
                        double* out_sum);
 
+/* ---- robot-cube occupancy for the trajectory planner ----------------
+ * out_flags[q] = 1 iff some mesh vertex lies inside the axis-aligned cube [p_q - half, p_q + half] (float64,
+ * inclusive), for all Q positions at once.  Replaces AutoTrajectoryGenerator._is_point_inside_mesh
+ * (trajectory/auto_trajectory_generator.py:219-238), which the reference evaluates position by position over
+ * every vertex for the free-space grid (:129-139) and for every waypoint of every candidate (:345-356). */
+typedef struct lrc_occ lrc_occ;
+int lrc_occ_create(lrc_ctx* ctx, const double* verts3, uint64_t num_vertices, lrc_occ** out_occ);
+int lrc_occ_destroy(lrc_occ* occ);
+int lrc_occ_query(lrc_occ* occ, const double* points3, uint64_t num_points, double half, uint8_t* out_flags);
+
 /* Number of traversal-kernel launches and rays issued on this scene so far (bench bookkeeping). */
 int lrc_scene_get_counters(const lrc_scene* scene, uint64_t* launches, uint64_t* rays);
 

@@ -30,6 +30,7 @@ SYMBOLS = (
     "lrc_compact", "lrc_compact_dev", "lrc_cloud_from_ranges_dev",
     "lrc_nn_create", "lrc_nn_destroy", "lrc_nn_query", "lrc_nn_query_dev",
     "lrc_min_distances", "lrc_rbf_kernel_sum",
+    "lrc_occ_create", "lrc_occ_destroy", "lrc_occ_query",
 )
 
 
@@ -96,6 +97,9 @@ def load():
         "lrc_cast_segments_dev": [vp, vp, u64, vp, u64, vp, dbl, C.POINTER(LrcHits), vp],
         "lrc_scan_poses": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcHits)],
         "lrc_scan_poses_dev": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcHits), vp],
+        "lrc_occ_create": [vp, vp, u64, C.POINTER(vp)],
+        "lrc_occ_destroy": [vp],
+        "lrc_occ_query": [vp, vp, u64, dbl, vp],
         "lrc_min_distances": [vp, vp, u64, vp, u64, vp],
         "lrc_rbf_kernel_sum": [vp, vp, u64, vp, u64, dbl, C.POINTER(dbl)],
         "lrc_nn_create": [vp, vp, u64, dbl, C.POINTER(vp)],

@@ -336,3 +336,34 @@ def bake_triangle_labels(index, vertices, triangles, semantic, instance):
     cen = (v[f[:, 0]] + v[f[:, 1]] + v[f[:, 2]]) / 3.0
     nearest = index.query(cen.astype(np.float32))
     return (np.asarray(semantic)[nearest].astype(np.uint16), np.asarray(instance)[nearest].astype(np.uint16))
+
+
+class OccupancyIndex:
+    """Mesh vertices resident in HBM for the planner's robot-cube test (reference:
+    trajectory/auto_trajectory_generator.py:219-238)."""
+
+    def __init__(self, ctx, vertices):
+        self._lib = _capi.load()
+        self.ctx = ctx
+        v = np.ascontiguousarray(np.asarray(vertices), dtype=np.float64).reshape(-1, 3)
+        h = C.c_void_p()
+        check(self._lib.lrc_occ_create(ctx._h, _ptr(v), len(v), C.byref(h)), "lrc_occ_create")
+        self._h = h
+
+    def occupied(self, points, half):
+        """bool (Q,): does the cube [p - half, p + half] contain a vertex?"""
+        p = np.ascontiguousarray(np.asarray(points), dtype=np.float64).reshape(-1, 3)
+        flags = np.zeros(len(p), dtype=np.uint8)
+        check(self._lib.lrc_occ_query(self._h, _ptr(p), len(p), float(half), _ptr(flags)), "lrc_occ_query")
+        return flags.astype(bool)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lrc_occ_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

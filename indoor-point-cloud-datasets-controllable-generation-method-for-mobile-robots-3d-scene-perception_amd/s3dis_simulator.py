@@ -18,7 +18,7 @@ import numpy as np
 from containers import RoomBounds, S3DISScene, S3DISSimFrame, S3DISSimScene, ScanQuality
 from lidar import (DualAxisLidarIntrinsics, Indoor8LineLidarIntrinsics, create_lidar)
 from raycast_engine import RaycastEngineCPU, RaycastEngineGPU
-from trajectory import Waypoint, poses_from_waypoints
+from trajectory import AutoTrajectoryGenerator, Waypoint, poses_from_waypoints
 
 
 class S3DISSimulator:
@@ -31,6 +31,7 @@ class S3DISSimulator:
         self.scene: Optional[S3DISScene] = None
         self.lidar_config = None
         self.raycast_engine = None
+        self.auto_trajectory_generator = None
         self._initialize_components()
 
     def _initialize_components(self):
@@ -55,7 +56,28 @@ class S3DISSimulator:
         if len(np.asarray(mesh.vertices)) == 0:
             raise ValueError("Failed to load mesh: no vertices")
         self.scene = S3DISScene(scene_name or "scene", mesh, RoomBounds.from_vertices(mesh.vertices))
+        # same planner settings as the reference (s3dis_simulator.py:127): reduced radius for narrow spaces
+        self.auto_trajectory_generator = AutoTrajectoryGenerator(robot_radius=0.15, context=self.raycast_engine.ctx)
         return self.scene
+
+    def generate_auto_trajectory(self, num_waypoints: int = 20):
+        """Planned trajectory for the loaded scene (reference s3dis_simulator.py:132-167)."""
+        if self.scene is None:
+            raise ValueError("Scene not loaded. Call load_scene() first.")
+        b = self.scene.room_bounds
+        bounds = {"x_min": b.x_min, "x_max": b.x_max, "y_min": b.y_min, "y_max": b.y_max,
+                  "z_min": b.z_min, "z_max": b.z_max}
+        return self.auto_trajectory_generator.generate_optimal_trajectory(
+            mesh=self.scene.room_mesh, room_bounds=bounds, num_waypoints=num_waypoints)
+
+    def run_auto_simulation(self, scene, num_waypoints: int = 20, output_dir=None):
+        """load_scene -> generate_auto_trajectory -> run_simulation (-> save_results), reference :407-444."""
+        self.load_scene(scene)
+        waypoints, analysis = self.generate_auto_trajectory(num_waypoints)
+        sim_scene = self.run_simulation(waypoints)
+        if output_dir is not None:
+            sim_scene.save_results(output_dir)
+        return sim_scene, waypoints, analysis
 
     # ---- the scan stage ---------------------------------------------------------------------------
     def _quality(self, points, incident_angles, total_points_per_scan, room_volume) -> ScanQuality:

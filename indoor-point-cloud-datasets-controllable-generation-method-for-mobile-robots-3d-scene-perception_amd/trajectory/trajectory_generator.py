@@ -41,6 +41,22 @@ class Waypoint:
         return f"Waypoint(x={self.x:.2f}, y={self.y:.2f}, z={self.z:.2f}, yaw={self.yaw:.2f})"
 
 
+@dataclass
+class TrajectoryQuality:
+    """Quality record of a planned trajectory (reference: trajectory/trajectory_generator.py:64-81)."""
+    coverage_ratio: float
+    path_length: float
+    turn_count: int
+    efficiency: float
+    collision_count: int
+    smoothness: float
+
+    def to_dict(self):
+        return {"coverage_ratio": self.coverage_ratio, "path_length": self.path_length,
+                "turn_count": self.turn_count, "efficiency": self.efficiency,
+                "collision_count": self.collision_count, "smoothness": self.smoothness}
+
+
 def poses_from_waypoints(waypoints: List[Waypoint]) -> np.ndarray:
     """(P,4,4) float64 stack of ``to_pose_matrix()``."""
     if len(waypoints) == 0:

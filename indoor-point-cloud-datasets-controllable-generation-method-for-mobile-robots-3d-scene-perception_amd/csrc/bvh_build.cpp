@@ -76,6 +76,7 @@ struct Builder {
     std::atomic<int64_t> next_node{0};
     int max_leaf = kMaxLeaf;
     int fork_depth = 0;                      // fork while depth < fork_depth
+    int depth_cap = kMaxDepth - 1;           // deepest allowed leaf (<= kMaxDepth - 1)
     std::atomic<uint32_t> max_depth{0};
     std::atomic<uint32_t> max_leaf_seen{0};
     std::atomic<uint64_t> num_leaves{0};
@@ -91,7 +92,7 @@ struct Builder {
         return ceil_log2_u64(leaves ? leaves : 1);
     }
     // can a subtree with n prims whose root sits at `depth` finish with leaf depth <= kMaxDepth-1 ?
-    bool fits(uint64_t n, int depth) const { return depth + median_height(n) <= kMaxDepth - 1; }
+    bool fits(uint64_t n, int depth) const { return depth + median_height(n) <= depth_cap; }
 
     int64_t make_leaf(uint64_t begin, uint64_t end, int depth) {
         uint64_t cnt = end - begin;
@@ -228,6 +229,13 @@ void build_bvh(const float* verts3, uint64_t V, const uint32_t* tris3, uint64_t 
     for (int k = 0; k < 3; ++k) { o.bounds_lo[k] = all.lo[k]; o.bounds_hi[k] = all.hi[k]; }
 
     b.nodes.resize(T + 1);                   // inner nodes < leaves <= T
+    {
+        // every level of leaf depth costs 256 B of LDS stack per wave in the trace kernel; SAH trees of gridded
+        // meshes are only a few levels deeper than the balanced tree, so cap the depth at balanced + slack
+        const int balanced = b.median_height(T);
+        int cap = opt.depth_slack >= 0 ? balanced + opt.depth_slack : kMaxDepth - 1;
+        b.depth_cap = std::min(std::max(cap, balanced), kMaxDepth - 1);
+    }
     {
         unsigned hw = std::thread::hardware_concurrency();
         int threads = opt.threads > 0 ? opt.threads : (int)std::min<unsigned>(hw ? hw : 1u, 16u);

@@ -597,6 +597,7 @@ int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32
     lrc::BuildOptions opt;
     if (const char* e = std::getenv("LRC_MAX_LEAF")) opt.max_leaf = std::atoi(e);
     if (const char* e = std::getenv("LRC_BFS_NODES")) opt.bfs_nodes = std::atoi(e);
+    if (const char* e = std::getenv("LRC_DEPTH_SLACK")) opt.depth_slack = std::atoi(e);
     auto t0 = std::chrono::steady_clock::now();
     try {
         lrc::build_bvh(verts3, V, tris3, T, tri_sem, tri_ins, opt, &h);

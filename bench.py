@@ -186,10 +186,20 @@ def main():
 
     k_events = []
     state = {"i": 0, "pending": None}
+    if gathers is not None:
+        # the rebuild is HBM-bound, the trace is latency/VALU-bound: run the rebuild of scan i-1 on a second stream
+        # so that it overlaps the trace of scan i+1 (and the collective of scan i)
+        side = torch.cuda.Stream(device=dev)
+        rebuilt = [None, None]                   # event: the rebuild that last READ gathers[k].all_pairs is done
 
-    def rebuild(g):
-        g.wait()                     # the compute stream waits for the collective
-        ctx.cloud_from_ranges_dev(d_all_poses, d_dirs, g.all_pairs, cloud, counts, stream)
+    def rebuild(k):
+        g = gathers[k]
+        with torch.cuda.stream(side):
+            g.work.wait()                        # the side stream waits for the collective of that scan
+            ctx.cloud_from_ranges_dev(d_all_poses, d_dirs, g.all_pairs, cloud, counts, side.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        rebuilt[k] = ev
 
     def step(timed):
         if timed:
@@ -202,22 +212,30 @@ def main():
                 k_events.append((e0, e1))
             ctx.compact_dev(P, N, io, stream)
             return
-        g = gathers[state["i"] % 2]
+        k = state["i"] % 2
         state["i"] += 1
+        g = gathers[k]
+        main = torch.cuda.current_stream()
+        if g.work is not None:
+            g.work.wait()                        # the collective that last read this send slab (scan i-2) is done
+        if rebuilt[k] is not None:
+            main.wait_event(rebuilt[k])          # ... and so is the rebuild that read its receive buffer
         hits.struct.t_label = g.slab.data_ptr()
         scene.scan_poses_dev(d_poses, d_dirs, hits, sensor.max_range, stream)
         if timed:
             e1.record()
             k_events.append((e0, e1))
-        g.gather(async_op=True)
+        g.gather(async_op=True)                  # ONE RCCL all-gather per scan, ordered after the trace
         if state["pending"] is not None:
-            rebuild(state["pending"])            # cloud of the previous scan, while this scan's pairs travel
-        state["pending"] = g
+            rebuild(state["pending"])            # cloud of the previous scan: other stream, overlaps the next trace
+        state["pending"] = k
 
     def drain():
-        if gathers is not None and state["pending"] is not None:
-            rebuild(state["pending"])
-            state["pending"] = None
+        if gathers is not None:
+            if state["pending"] is not None:
+                rebuild(state["pending"])
+                state["pending"] = None
+            torch.cuda.current_stream().wait_stream(side)
 
     def barrier():
         drain()

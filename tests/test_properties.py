@@ -1,6 +1,8 @@
 """Property tests (hypothesis): adversarial small scenes -- snapped coordinates (axis-aligned, coincident and
 degenerate triangles), rays with zero direction components, origins on vertices/planes -- where the closest hit
 must be the same for brute force (the definition), the oracle's own BVH and, on the GPU, the HIP traversal."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
@@ -35,7 +37,8 @@ def scenes(draw):
     return v, f.astype(np.int32), np.concatenate([o, d], 1).astype(np.float32)
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=int(os.environ.get("LRC_HYPOTHESIS_EXAMPLES", 60)), deadline=None, derandomize="LRC_HYPOTHESIS_EXAMPLES" not in os.environ,
+          suppress_health_check=list(HealthCheck))
 @given(scenes())
 def test_oracle_bvh_equals_definition(scene):
     v, f, rays = scene
@@ -49,7 +52,8 @@ def test_oracle_bvh_equals_definition(scene):
 
 
 @pytest.mark.gpu
-@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=int(os.environ.get("LRC_HYPOTHESIS_EXAMPLES", 40)), deadline=None, derandomize="LRC_HYPOTHESIS_EXAMPLES" not in os.environ,
+          suppress_health_check=list(HealthCheck))
 @given(scenes())
 def test_hip_equals_definition(scene):
     import lidarcast

@@ -298,6 +298,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "trace_kernel<GEN=true>", "kernel_ms": kernel_ms, "bytes_per_ray": bpr,
                 "rays_per_launch": n, "algorithmic_bytes_per_launch": n * bpr,
+                "traffic_GBps": None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9,
+                "occupancy": dict(scene.occupancy(), max_waves_per_cu=32),
                 "note": "achieved = algorithmic bytes (SURVEY 8(d): 36 B record + 64 B x ceil(log2(T/4)) descent + "
                         "144 B leaf, per ray) / kernel time; neighbouring rays re-use nodes from L1/L2/Infinity "
                         "Cache, so it can exceed the HBM peak. traffic = measured HBM-side bytes per launch "

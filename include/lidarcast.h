@@ -261,6 +261,10 @@ int lrc_occ_create(lrc_ctx* ctx, const double* verts3, uint64_t num_vertices, lr
 int lrc_occ_destroy(lrc_occ* occ);
 int lrc_occ_query(lrc_occ* occ, const double* points3, uint64_t num_points, double half, uint8_t* out_flags);
 
+/* Resident waves per CU the runtime grants the pose-batched trace kernel on this scene (its LDS stack is sized by
+ * the tree depth), its VGPR count and LDS bytes per wave: the occupancy figure bench.py reports. */
+int lrc_scene_get_occupancy(const lrc_scene* scene, int* waves_per_cu, int* vgprs, int* lds_bytes);
+
 /* Number of traversal-kernel launches and rays issued on this scene so far (bench bookkeeping). */
 int lrc_scene_get_counters(const lrc_scene* scene, uint64_t* launches, uint64_t* rays);
 

@@ -719,6 +719,21 @@ static int launch_trace(lrc_scene* s, TraceParams& p, bool gen, hipStream_t st) 
     return LRC_OK;
 }
 
+int lrc_scene_get_occupancy(const lrc_scene* s, int* waves_per_cu, int* vgprs, int* lds_bytes) {
+    if (!s) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_get_occupancy: scene is NULL");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    const uint32_t depth = s->info.max_depth < 1 ? 1 : s->info.max_depth;
+    const size_t lds = (size_t)depth * kTBlock * sizeof(int);
+    int blocks = 0;
+    LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<true, 1, true, false, false>, kTBlock, lds));
+    hipFuncAttributes attr;
+    LRC_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trace_kernel<true, 1, true, false, false>)));
+    if (waves_per_cu) *waves_per_cu = blocks * (kTBlock / 64);
+    if (vgprs) *vgprs = attr.numRegs;
+    if (lds_bytes) *lds_bytes = (int)lds;
+    return LRC_OK;
+}
+
 int lrc_cast_dev(lrc_scene* s, const float* d_rays6, uint64_t n, const double* center3,
                  double max_range, const lrc_hits* d_out, void* stream) {
     if (!s || !d_out) return fail(LRC_ERR_INVALID_ARG, "lrc_cast_dev: NULL scene or output");

@@ -24,7 +24,7 @@ SYMBOLS = (
     "lrc_version", "lrc_last_error", "lrc_device_count",
     "lrc_ctx_create", "lrc_ctx_destroy", "lrc_ctx_synchronize",
     "lrc_scene_create", "lrc_scene_destroy", "lrc_scene_get_info", "lrc_scene_export_bvh",
-    "lrc_scene_get_counters", "lrc_scene_set_options",
+    "lrc_scene_get_counters", "lrc_scene_set_options", "lrc_scene_get_occupancy",
     "lrc_cast", "lrc_cast_dev", "lrc_cast_segments", "lrc_cast_segments_dev",
     "lrc_scan_poses", "lrc_scan_poses_dev",
     "lrc_compact", "lrc_compact_dev", "lrc_cloud_from_ranges_dev",
@@ -91,6 +91,7 @@ def load():
         "lrc_scene_export_bvh": [vp, vp, vp],
         "lrc_scene_get_counters": [vp, C.POINTER(u64), C.POINTER(u64)],
         "lrc_scene_set_options": [vp, C.POINTER(LrcScanOptions)],
+        "lrc_scene_get_occupancy": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
         "lrc_cast": [vp, vp, u64, vp, dbl, C.POINTER(LrcHits)],
         "lrc_cast_dev": [vp, vp, u64, vp, dbl, C.POINTER(LrcHits), vp],
         "lrc_cast_segments": [vp, vp, u64, vp, u64, vp, dbl, C.POINTER(LrcHits)],

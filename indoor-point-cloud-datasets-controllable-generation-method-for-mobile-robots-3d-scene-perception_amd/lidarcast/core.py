@@ -208,6 +208,12 @@ class Scene:
         self._noise_keepalive = None
         check(self._lib.lrc_scene_set_options(self._h, None), "lrc_scene_set_options")
 
+    def occupancy(self):
+        """dict(waves_per_cu, vgprs, lds_bytes_per_wave) of the pose-batched trace kernel on this scene."""
+        w, v, l = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(self._lib.lrc_scene_get_occupancy(self._h, C.byref(w), C.byref(v), C.byref(l)), "lrc_scene_get_occupancy")
+        return {"waves_per_cu": w.value, "vgprs": v.value, "lds_bytes_per_wave": l.value}
+
     def counters(self):
         a, b = C.c_uint64(0), C.c_uint64(0)
         check(self._lib.lrc_scene_get_counters(self._h, C.byref(a), C.byref(b)), "lrc_scene_get_counters")

@@ -4,7 +4,8 @@
 One "step" = one pass of the hot path over the whole trajectory batch, inputs resident in HBM:
   trace kernel (rays generated in-kernel from 64 poses x the 32x2048 direction table, BVH
   traversal, hit write-back of t/prim/normal/point/sem/ins, range filter)  ->  stable compaction
-  into the scene cloud (np.vstack order)  ->  for N > 1, one RCCL all-gather of the clouds.
+  into the scene cloud (np.vstack order); for N > 1 instead: one RCCL all-gather of the hit triangle ids and the
+  rebuild of the whole scene cloud on every GPU.
 Weak scaling: every rank scans its own 64 poses of a 64*N-pose trajectory over a replica of the scene.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the trace kernel with the algorithmic bytes per ray
@@ -125,6 +126,10 @@ def main():
     ap.add_argument("--dist-selftest", action="store_true",
                     help="run the N>1 code path (RCCL all-gather, double buffering) with world size 1 and check "
                          "the assembled cloud against the local one")
+    ap.add_argument("--virtual-world", type=int, default=1,
+                    help="diagnostic, with --dist-selftest only: size the gathered buffers and the cloud rebuild for "
+                         "this many ranks (the other ranks' slabs are scanned once before the timed region), to "
+                         "measure what the N-GPU step costs a GPU apart from the link transfer")
     args = ap.parse_args()
 
     import torch
@@ -155,48 +160,62 @@ def main():
     scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
     info = scene.info
     sensor = c3_sensor()
-    poses = c3_poses(rank, world)
+    if args.virtual_world > 1 and not (args.dist_selftest and world == 1):
+        raise SystemExit("--virtual-world needs --dist-selftest on one GPU")
+    job = world if world > 1 else max(args.virtual_world, 1)      # ranks the buffers and the rebuild are sized for
+    poses = c3_poses(rank, job)
     dirs = IndoorLidar(intrinsics=sensor, pose=np.eye(4)).sensor_directions()
     P, N = poses.shape[0], dirs.shape[0]
     n = P * N
     d_poses = torch.from_numpy(poses.reshape(P, 16)).to(dev)
     d_dirs = torch.from_numpy(dirs).to(dev)
     dist_path = world > 1 or args.dist_selftest
-    want = ("t", "prim", "normal3", "point3", "sem", "ins", "tile_count") + (("t_label",) if dist_path else ())
+    want = ("t", "prim", "normal3", "point3", "sem", "ins", "tile_count")
     hits = lidarcast.DeviceHits(n, dev, want=want)
     # scene cloud: compacted 16-byte rows (x, y, z, sem|ins<<16) in np.vstack order + per-pose counts.
-    cloud = torch.empty((n * world, 4), dtype=torch.float32, device=dev)
-    counts = torch.zeros(P * world, dtype=torch.int64, device=dev)
+    cloud = torch.empty((n * job, 4), dtype=torch.float32, device=dev)
+    counts = torch.zeros(P * job, dtype=torch.int64, device=dev)
     io = LrcCompactIO()
     io.t, io.point3 = hits["t"].data_ptr(), hits["point3"].data_ptr()
     io.sem, io.ins = hits["sem"].data_ptr(), hits["ins"].data_ptr()
     io.tile_count = hits["tile_count"].data_ptr()
     io.counts, io.out_xyzl = counts.data_ptr(), cloud.data_ptr()
     stream = torch.cuda.current_stream().cuda_stream
+    own_prim, own_tile_count = hits.struct.prim, hits.struct.tile_count
     if dist_path:
-        # N > 1: every rank scans its own poses, ONE all-gather per scan moves the 8-byte (t, label) pairs
-        # (the trace kernel writes them straight into the send slab), and every rank rebuilds the whole cloud
-        # from the gathered pairs.  Two buffer sets: the collective of scan i overlaps the trace of scan i+1.
-        from lidarcast.distributed import RangeGather
-        gathers = [RangeGather(n, dist, dev) for _ in range(2)]
-        all_poses = np.concatenate([c3_poses(r, world) for r in range(world)]).reshape(P * world, 16)
+        # N > 1: every rank scans its own poses, ONE all-gather per scan moves the 4-byte triangle id of every ray
+        # and the per-wave keep counts (the trace kernel writes both straight into the send slab), and every rank
+        # rebuilds the whole cloud from the gathered ids (t recomputed with the scan's own ray/triangle test).
+        # Two buffer sets: the collective of scan i overlaps the trace of scan i+1.
+        from lidarcast.distributed import PrimGather
+        gathers = [PrimGather(P, N, dist, dev, world=job) for _ in range(2)]
+        all_poses = np.concatenate([c3_poses(r, job) for r in range(job)]).reshape(P * job, 16)
         d_all_poses = torch.from_numpy(all_poses).to(dev)
+        for g in gathers:                         # virtual ranks: their slabs are filled once, outside the timing
+            for v in range(1, job if world == 1 else 1):
+                hits.struct.prim = g.all_slabs[v * g.words:].data_ptr()
+                hits.struct.tile_count = g.all_slabs[v * g.words + g.n:].data_ptr()
+                scene.scan_poses_dev(d_all_poses[v * P:(v + 1) * P], d_dirs, hits, sensor.max_range, stream)
+        torch.cuda.synchronize()
     else:
         gathers = None
 
     k_events = []
     state = {"i": 0, "pending": None}
     if gathers is not None:
-        # the rebuild is HBM-bound, the trace is latency/VALU-bound: run the rebuild of scan i-1 on a second stream
-        # so that it overlaps the trace of scan i+1 (and the collective of scan i)
+        # The rebuild of scan i-1 goes to a second stream, next to the trace of scan i+1 and the collective of scan i.
+        # (Measured with buffers sized for 8 ranks: two streams 0.675 ms per step, one stream 0.730, the rebuild folded
+        # into the trace launch as a per-wave tail 0.717 -- both kernels load the vector L1 path, so what overlap
+        # there is comes from the launch gaps and the tails of the two grids.)
         side = torch.cuda.Stream(device=dev)
-        rebuilt = [None, None]                   # event: the rebuild that last READ gathers[k].all_pairs is done
+        rebuilt = [None, None]                   # event: the rebuild that last READ gathers[k].all_slabs is done
 
     def rebuild(k):
         g = gathers[k]
         with torch.cuda.stream(side):
             g.work.wait()                        # the side stream waits for the collective of that scan
-            ctx.cloud_from_ranges_dev(d_all_poses, d_dirs, g.all_pairs, cloud, counts, side.cuda_stream)
+            scene.cloud_from_prims_dev(d_all_poses, d_dirs, g.all_prims, cloud, counts, g.all_tile_counts,
+                                       poses_per_slab=P, slab_stride_bytes=g.stride_bytes, stream=side.cuda_stream)
             ev = torch.cuda.Event()
             ev.record(side)
         rebuilt[k] = ev
@@ -220,7 +239,8 @@ def main():
             g.work.wait()                        # the collective that last read this send slab (scan i-2) is done
         if rebuilt[k] is not None:
             main.wait_event(rebuilt[k])          # ... and so is the rebuild that read its receive buffer
-        hits.struct.t_label = g.slab.data_ptr()
+        hits.struct.prim = g.prim.data_ptr()     # the 36-byte record is complete; its id column IS the send slab
+        hits.struct.tile_count = g.tile_count.data_ptr()
         scene.scan_poses_dev(d_poses, d_dirs, hits, sensor.max_range, stream)
         if timed:
             e1.record()
@@ -257,16 +277,27 @@ def main():
         elapsed = float(tmax.item())
 
     if args.dist_selftest:
-        # the cloud rebuilt from the gathered pairs must equal the local compaction, bit for bit
+        # the cloud rebuilt from the gathered triangle ids must equal the local compaction, bit for bit
         k = int(counts.sum().item())
         rebuilt = cloud[:k].clone()
         rebuilt_counts = counts.clone()
-        ctx.compact_dev(P, N, io, stream)
-        torch.cuda.synchronize()
-        assert int(counts.sum().item()) == k and torch.equal(rebuilt_counts, counts), "per-pose counts differ"
-        assert torch.equal(rebuilt.view(torch.int32), cloud[:k].view(torch.int32)), "rebuilt cloud differs"
-        print(f"dist selftest ok: {k} rows rebuilt from gathered (t,label) pairs == local compaction, world {world}",
-              file=sys.stderr)
+        hits.struct.prim, hits.struct.tile_count = own_prim, own_tile_count
+        local = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        local_counts = torch.zeros(P, dtype=torch.int64, device=dev)
+        io.out_xyzl, io.counts = local.data_ptr(), local_counts.data_ptr()
+        row = 0
+        for v in range(job):
+            scene.scan_poses_dev(d_all_poses[v * P:(v + 1) * P], d_dirs, hits, sensor.max_range, stream)
+            ctx.compact_dev(P, N, io, stream)
+            torch.cuda.synchronize()
+            kv = int(local_counts.sum().item())
+            assert torch.equal(rebuilt_counts[v * P:(v + 1) * P], local_counts), f"per-pose counts differ, rank {v}"
+            assert torch.equal(rebuilt[row:row + kv].view(torch.int32), local[:kv].view(torch.int32)), \
+                f"rebuilt cloud differs in the poses of rank {v}"
+            row += kv
+        assert row == k, "row totals differ"
+        print(f"dist selftest ok: {k} rows rebuilt from gathered triangle ids == local compaction, "
+              f"world {world}, buffers sized for {job} ranks", file=sys.stderr)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in k_events]))
     hits_total = int(counts.sum().item())
     total_rays = n * world * args.steps
@@ -285,13 +316,14 @@ def main():
                 "workload": f"C3: create_dense_32line x horizontal_res=2048 ({N} rays/pose) x {P} poses per GPU "
                             f"(straight line, yaw 0) over {args.scene} (procedural stand-in for an S3DIS "
                             f"Area_6 office mesh, 2 cm tessellation, T={info['num_triangles']})",
-                "rays_per_step_per_gpu": n, "hit_fraction": hits_total / (n * (world if dist_path else 1)),
+                **({"virtual_world": job} if world == 1 and job > 1 else {}),
+                "rays_per_step_per_gpu": n, "hit_fraction": hits_total / (n * (job if dist_path else 1)),
                 "bvh": {"nodes": info["num_nodes"], "depth": info["max_depth"],
                         "build_ms": round(info["build_ms"], 1), "device_MB": round(info["device_bytes"] / 1e6, 1)},
                 "step": "in-kernel ray generation + BVH traversal + hit write-back (36 B/ray) + "
                         + ("stable compaction into the scene cloud (16 B/hit)" if world == 1 else
-                           "one RCCL all-gather of the (t,label) pairs (8 B/ray) + rebuild of the whole scene "
-                           "cloud (16 B/hit, all ranks' poses) on every GPU"),
+                           "one RCCL all-gather of the hit triangle ids (4 B/ray + 4 B per 64 rays of keep counts) + "
+                           "rebuild of the whole scene cloud (16 B/hit, all ranks' poses) on every GPU"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -226,6 +226,25 @@ int lrc_cloud_from_ranges_dev(lrc_ctx* ctx, const double* d_poses16, uint64_t nu
                               const double* d_dirs3, uint64_t rays_per_pose, const void* d_t_label,
                               float* d_out_xyzl, uint64_t* d_counts, void* stream);
 
+/* The same rebuild from 4 bytes per ray: the hit triangle's row (lrc_hits.prim, Open3D's primitive_ids of
+ * raycast_engine_cpu.py:51; LRC_INVALID_PRIM = no return).  A closest hit is a pure function of (pose, direction,
+ * triangle), so a rank that holds the scene replica recomputes t with the scan's own ray/triangle test, bit for
+ * bit, and the point and the triangle's labels from it.  This is what the multi-GPU all-gather moves (DESIGN.md
+ * section 6): xGMI links, not the kernels, bound the multi-GPU job.  Not available while a range_noise option is
+ * set (the noise is not a function of the triangle): use lrc_cloud_from_ranges_dev then.
+ *   d_prim       : entry (pose p, ray i) at word (p / poses_per_slab) * slab_stride_bytes/4
+ *                  + (p % poses_per_slab) * rays_per_pose + i -- the gathered send slabs of several ranks in place;
+ *                  poses_per_slab = 0 means one contiguous (num_poses * rays_per_pose) array
+ *   d_tile_count : nullable; the senders' lrc_hits.tile_count (kept rays per aligned run of 64), laid out in the
+ *                  same slabs: tile k of slab r at d_tile_count[r * slab_stride_bytes/4 + k].  Saves the counting
+ *                  pass; needs rays_per_pose % 64 == 0
+ *   ranks that own fewer poses than poses_per_slab pad their slab with LRC_INVALID_PRIM entries (zero counts); the
+ *   pose table then has num_poses = slabs * poses_per_slab rows, padded ones arbitrary. */
+int lrc_cloud_from_prims_dev(lrc_scene* scene, const double* d_poses16, uint64_t num_poses,
+                             const double* d_dirs3, uint64_t rays_per_pose, const uint32_t* d_prim,
+                             const uint32_t* d_tile_count, uint64_t poses_per_slab, uint64_t slab_stride_bytes,
+                             float* d_out_xyzl, uint64_t* d_counts, void* stream);
+
 /* ---- nearest annotated point --------------------------------------
  * Exact 1-nearest-neighbour lookup of float32 query points in a float64 annotated cloud, float64 distances,
  * ties to the smaller row.  Replaces sklearn NearestNeighbors(n_neighbors=1, algorithm='ball_tree')

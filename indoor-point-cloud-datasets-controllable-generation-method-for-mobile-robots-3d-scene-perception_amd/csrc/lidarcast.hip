@@ -62,18 +62,28 @@ constexpr int kTBlock = LRC_TRACE_BLOCK;   // trace kernel workgroup (rays per t
 enum PoolSlot { kPoolRays = 0, kPoolT, kPoolPrim, kPoolNormal, kPoolPoint, kPoolSem, kPoolIns, kPoolInc,
                 kPoolPoses, kPoolDirs, kPoolOffs, kPoolCen, kPoolNoise, kPoolSlots };
 
+#ifndef LRC_REBUILD_R
+#define LRC_REBUILD_R 2      // tiles (of 64 entries) one wave of the cloud rebuild handles (1, 2, 4, 8 measured equal)
+#endif
+
 struct lrc_ctx {
     int device = 0;
     // staging buffers of the host-pointer entry points, grown on demand and reused (a per-waypoint caller
     // such as the reference loop, s3dis_simulator.py:254-264, would otherwise pay hipMalloc/hipFree per pose)
     void* pool[kPoolSlots] = {};
     size_t pool_cap[kPoolSlots] = {};
-    // compaction scratch (grown on demand, reused): per-tile counts and exclusive offsets
-    uint32_t* d_tile_off = nullptr;     // offset of a tile inside its super tile (1024 tiles)
-    uint32_t* d_tile_cnt = nullptr;
-    uint32_t* d_super_total = nullptr;  // kept entries per super tile
-    uint64_t* d_super_base = nullptr;   // exclusive prefix of d_super_total (+ grand total)
-    uint64_t tile_cap = 0;
+    // compaction scratch (grown on demand, reused): per-tile counts and exclusive offsets.  Two sets: the
+    // cloud rebuild of the multi-GPU path runs on its own stream next to the compaction of the local scan.
+    struct TileScratch {
+        uint32_t* d_tile_off = nullptr;     // offset of a tile inside its super tile (1024 tiles)
+        uint32_t* d_tile_cnt = nullptr;
+        uint32_t* d_super_total = nullptr;  // kept entries per super tile
+        uint64_t* d_super_base = nullptr;   // exclusive prefix of d_super_total (+ grand total)
+        uint64_t tile_cap = 0;
+        double* d_dirs_soa = nullptr;       // direction table transposed to x[N] y[N] z[N] (cloud rebuild only)
+        uint64_t dirs_cap = 0;
+    };
+    TileScratch compact_scratch, cloud_scratch;
 };
 
 struct lrc_scene {
@@ -82,6 +92,7 @@ struct lrc_scene {
     float4* d_tris = nullptr;
     uint32_t* d_slot_prim = nullptr;
     uint32_t* d_slot_label = nullptr;
+    float4* d_prim_plane = nullptr;   // per caller's triangle row: (v0, label bits), (Ng, 0): lrc_cloud_from_prims_dev
     lrc_scene_info info{};
     lrc_scan_options opts{};          // sticky opt-in options (lrc_scene_set_options)
     uint64_t launches = 0, rays = 0;
@@ -91,6 +102,22 @@ struct lrc_scene {
 // device code
 // ------------------------------------------------------------------------------------------------
 namespace {
+
+// A cloud rebuild from gathered triangle ids (lrc_cloud_from_prims_dev), as a kernel argument block.
+struct RebuildParams {
+    const double* __restrict__ poses16;
+    const double* __restrict__ dirs_soa;     // direction table transposed to x[N] y[N] z[N]
+    const uint32_t* __restrict__ prims;      // entry (pose p, ray i): slab p / pps, word (p % pps) * seg_len + i
+    uint32_t pps;
+    uint64_t stride;                         // words between slabs
+    uint32_t seg_len, tps, ntiles, nseg;
+    const float4* __restrict__ plane;
+    uint32_t num_prims;
+    const uint32_t* __restrict__ tile_off;
+    const uint64_t* __restrict__ super_base;
+    float4* __restrict__ out_xyzl;
+    uint64_t* __restrict__ counts;
+};
 
 struct TraceParams {
     const float4* nodes;
@@ -133,6 +160,86 @@ typedef __attribute__((address_space(4))) const float cfloat;      // constant a
 __device__ __forceinline__ F4 ld_uniform(const float4* gp) {
     cfloat* c = (cfloat*)gp;
     return F4{c[0], c[1], c[2], c[3]};
+}
+
+// ---- cloud rebuild from triangle ids: the device part ----
+// R independent entries per lane: all ids are fetched first, then all plane records, then the arithmetic -- a chain
+// of dependent gathers wants loads in flight per wave.  plane: 2 x float4 per triangle row: (v0, label bits), (Ng, 0)
+// -- all a known hit needs to give t again.  Tiles [tile0, tile0 + R) below `limit` are processed.
+template <int R>
+__device__ __forceinline__ void rebuild_tiles(const RebuildParams& q, uint32_t tile0, uint32_t limit, uint32_t lane) {
+    uint32_t seg[R], idx[R], prim[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const uint32_t tile = tile0 + k;
+        prim[k] = LRC_INVALID_PRIM;
+        seg[k] = 0; idx[k] = 0;
+        if (tile < limit) {
+            seg[k] = tile / q.tps;
+            const uint32_t chunk = tile - seg[k] * q.tps, sb = seg[k] / q.pps;
+            idx[k] = chunk * 64u + lane;
+            if (idx[k] < q.seg_len)     // read once: streaming load
+                prim[k] = __builtin_nontemporal_load(q.prims + (uint64_t)sb * q.stride +
+                                                     (uint64_t)(seg[k] - sb * q.pps) * q.seg_len + idx[k]);
+        }
+    }
+    float4 pa[R], pb[R];
+    double da[R], db[R], dc[R];
+    uint64_t dst[R];
+    bool keep[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        keep[k] = prim[k] != LRC_INVALID_PRIM;
+        const unsigned long long m = __ballot(keep[k]);
+        pa[k] = pb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        da[k] = db[k] = dc[k] = 0.0;
+        dst[k] = 0;
+        if (keep[k]) {
+            const uint32_t tile = tile0 + k;
+            dst[k] = q.super_base[tile >> 10] + q.tile_off[tile] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+            da[k] = q.dirs_soa[idx[k]];
+            db[k] = q.dirs_soa[(size_t)q.seg_len + idx[k]];
+            dc[k] = q.dirs_soa[2 * (size_t)q.seg_len + idx[k]];
+            if (prim[k] < q.num_prims) {   // an id that is not a triangle of this scene: zero plane, never a wild read
+                pa[k] = q.plane[(size_t)prim[k] * 2];
+                pb[k] = q.plane[(size_t)prim[k] * 2 + 1];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        if (!keep[k]) continue;
+        const double* M = q.poses16 + (size_t)seg[k] * 16;
+        // gen_ray, with the direction already in registers (same FMA chain, lrc_device.h)
+        V3 o, d, h, pt;
+        d.x = (float)__builtin_fma(dc[k], M[2], __builtin_fma(db[k], M[1], da[k] * M[0]));
+        d.y = (float)__builtin_fma(dc[k], M[6], __builtin_fma(db[k], M[5], da[k] * M[4]));
+        d.z = (float)__builtin_fma(dc[k], M[10], __builtin_fma(db[k], M[9], da[k] * M[8]));
+        o.x = (float)M[3]; o.y = (float)M[7]; o.z = (float)M[11];
+        // the sender's scan established that this ray hits this triangle; t is the expression tri_hit evaluates
+        // (T/|den| with T = Ng.(v0-O), den = Ng.D, sign-corrected), so v0 and Ng are all that is needed
+        const V3 v0{pa[k].x, pa[k].y, pa[k].z}, ng{pb[k].x, pb[k].y, pb[k].z};
+        const float den = dot3(ng, d);
+        const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+        const float t = xorsign(dot3(ng, sub3(v0, o)), sgn) / __builtin_fabsf(den);
+        hit_point(o, d, t, h, pt);
+        // streaming store: the rows are never read back here, and must not push the plane table out of the L2
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f row = {pt.x, pt.y, pt.z, pa[k].w};
+        __builtin_nontemporal_store(row, (v4f*)(q.out_xyzl + dst[k]));
+    }
+}
+
+// per-pose (segment) row counts from the scanned tile offsets: thread sg writes counts[sg]
+__device__ __forceinline__ void rebuild_counts(const RebuildParams& q, uint32_t first, uint32_t step) {
+    if (!q.counts) return;
+    const uint32_t nsuper = (q.ntiles + 1023u) / 1024u;
+    for (uint32_t sg = first; sg < q.nseg; sg += step) {
+        const uint64_t g0 = (uint64_t)sg * q.tps, g1 = g0 + q.tps;
+        const uint64_t o0 = g0 >= q.ntiles ? q.super_base[nsuper] : q.super_base[g0 >> 10] + q.tile_off[g0];
+        const uint64_t o1 = g1 >= q.ntiles ? q.super_base[nsuper] : q.super_base[g1 >> 10] + q.tile_off[g1];
+        q.counts[sg] = o1 - o0;
+    }
 }
 
 template <bool GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false>
@@ -337,6 +444,7 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
     if (p.out.sem) p.out.sem[gid] = (uint16_t)(label & 0xFFFFu);
     if (p.out.ins) p.out.ins[gid] = (uint16_t)(label >> 16);
     if (p.out.incident_deg) p.out.incident_deg[gid] = inc;
+
 }
 
 // ---- compaction -------------------------------------------------------------------------------
@@ -357,12 +465,19 @@ __global__ __launch_bounds__(kBlock) void compact_count_kernel(const float* t, u
 
 // Pass A: every workgroup scans its own run of 1024 tile counts (a "super tile" = 65536 entries):
 // tile_off[tile] = exclusive offset inside the super tile, super_total[b] = its sum.
-__global__ __launch_bounds__(1024) void compact_scan_kernel(const uint32_t* tile_cnt, uint32_t* tile_off,
+// The counts may sit in slabs (the gathered send buffers of several ranks): tiles_per_slab consecutive tiles, then the
+// next slab slab_stride words further on; a plain array is one slab.
+__global__ __launch_bounds__(1024) void compact_scan_kernel(const uint32_t* tile_cnt, uint64_t tiles_per_slab,
+                                                            uint64_t slab_stride, uint32_t* tile_off,
                                                             uint64_t ntiles, uint32_t* super_total) {
     __shared__ uint32_t s_wave[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const uint64_t tile = (uint64_t)blockIdx.x * 1024 + tid;
-    const uint32_t c = tile < ntiles ? tile_cnt[tile] : 0u;
+    uint32_t c = 0u;
+    if (tile < ntiles) {
+        const uint64_t sb = tile / tiles_per_slab;
+        c = tile_cnt[sb * slab_stride + (tile - sb * tiles_per_slab)];
+    }
     uint32_t incl = c;                       // inclusive scan inside the wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -501,6 +616,50 @@ __global__ __launch_bounds__(kBlock) void cloud_scatter_kernel(const double* pos
     out_xyzl[dst] = make_float4(pt.x, pt.y, pt.z, __uint_as_float(rec.y));
 }
 
+// ---- scene cloud from per-ray triangle ids ---------------------------------------------------------------
+// The hit of a pose-batched scan is a pure function of (pose, direction, triangle): a rank that holds the scene,
+// the poses and the direction table rebuilds t with the scan's own ray/triangle test (tri_hit, bit-identical) and
+// the point and label from it.  So the multi-GPU all-gather moves the 4-byte primitive id per ray -- Open3D's
+// primitive_ids -- and nothing else.  Rays the sender dropped (miss, range filter) carry LRC_INVALID_PRIM.
+// Entry (pose p, ray i) lives in slab p / pps at word (p % pps) * seg_len + i; slabs are `stride` words apart.
+
+__global__ __launch_bounds__(kBlock) void prim_count_kernel(const uint32_t* prims, uint64_t pps, uint64_t stride,
+                                                            uint64_t seg_len, uint64_t tps, uint64_t ntiles,
+                                                            uint32_t* tile_cnt) {
+    const uint64_t tile = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const uint64_t seg = tile / tps, chunk = tile - seg * tps;
+    const uint64_t i = chunk * 64 + (threadIdx.x & 63u);
+    const uint64_t sb = seg / pps;
+    bool keep = false;
+    if (i < seg_len) keep = prims[sb * stride + (seg - sb * pps) * seg_len + i] != LRC_INVALID_PRIM;
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63u) == 0) tile_cnt[tile] = (uint32_t)__popcll(m);
+}
+
+// (N,3) -> x[N] y[N] z[N]: the rebuild reads one direction per lane, and a 24-byte stride costs the vector L1 three
+// times the transactions of three unit-stride reads
+__global__ __launch_bounds__(kBlock) void dirs_transpose_kernel(const double* __restrict__ dirs3, uint32_t n,
+                                                                double* __restrict__ soa) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    soa[i] = dirs3[(size_t)i * 3];
+    soa[(size_t)n + i] = dirs3[(size_t)i * 3 + 1];
+    soa[2 * (size_t)n + i] = dirs3[(size_t)i * 3 + 2];
+}
+
+// Stand-alone rebuild: one wave per R consecutive tiles.
+// No XCD-contiguous remap of the tiles here: eight write streams a power of two apart land on the same HBM channels
+// in lock step -- measured 540 us against 330 us for round-robin workgroups.
+template <int R>
+__global__ __launch_bounds__(kBlock) void prim_scatter_kernel(const RebuildParams q) {
+    rebuild_counts(q, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock);
+    // everything that depends on the tile alone is wave-uniform: keep it on the scalar unit
+    const uint32_t tile0 = __builtin_amdgcn_readfirstlane((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * R);
+    if (tile0 >= q.ntiles) return;
+    rebuild_tiles<R>(q, tile0, q.ntiles, threadIdx.x & 63u);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -542,10 +701,13 @@ int lrc_ctx_destroy(lrc_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (int k = 0; k < kPoolSlots; ++k)
         if (ctx->pool[k]) (void)hipFree(ctx->pool[k]);
-    if (ctx->d_tile_off) (void)hipFree(ctx->d_tile_off);
-    if (ctx->d_tile_cnt) (void)hipFree(ctx->d_tile_cnt);
-    if (ctx->d_super_total) (void)hipFree(ctx->d_super_total);
-    if (ctx->d_super_base) (void)hipFree(ctx->d_super_base);
+    for (lrc_ctx::TileScratch* sc : {&ctx->compact_scratch, &ctx->cloud_scratch}) {
+        if (sc->d_tile_off) (void)hipFree(sc->d_tile_off);
+        if (sc->d_tile_cnt) (void)hipFree(sc->d_tile_cnt);
+        if (sc->d_super_total) (void)hipFree(sc->d_super_total);
+        if (sc->d_super_base) (void)hipFree(sc->d_super_base);
+        if (sc->d_dirs_soa) (void)hipFree(sc->d_dirs_soa);
+    }
     delete ctx;
     return LRC_OK;
 }
@@ -564,6 +726,7 @@ int lrc_scene_destroy(lrc_scene* s) {
     if (s->d_tris) (void)hipFree(s->d_tris);
     if (s->d_slot_prim) (void)hipFree(s->d_slot_prim);
     if (s->d_slot_label) (void)hipFree(s->d_slot_label);
+    if (s->d_prim_plane) (void)hipFree(s->d_prim_plane);
     delete s;
     return LRC_OK;
 }
@@ -628,8 +791,18 @@ int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32
         in.device_bytes += bytes;
         return LRC_OK;
     };
+    std::vector<float> prim_plane(T * 8, 0.0f);
+    for (size_t k = 0; k < h.slot_prim.size(); ++k) {
+        if (h.slot_prim[k] >= T) continue;
+        const float* r = h.tri_rec.data() + k * 12;       // v0 v1 v2 Ng
+        float* q = prim_plane.data() + (size_t)h.slot_prim[k] * 8;
+        q[0] = r[0]; q[1] = r[1]; q[2] = r[2];
+        std::memcpy(&q[3], &h.slot_label[k], 4);
+        q[4] = r[9]; q[5] = r[10]; q[6] = r[11];
+    }
     int rc;
-    if ((rc = upload((void**)&s->d_nodes, h.nodes.data(), h.nodes.size() * 4)) ||
+    if ((rc = upload((void**)&s->d_prim_plane, prim_plane.data(), prim_plane.size() * 4)) ||
+        (rc = upload((void**)&s->d_nodes, h.nodes.data(), h.nodes.size() * 4)) ||
         (rc = upload((void**)&s->d_tris, h.tri_rec.data(), h.tri_rec.size() * 4)) ||
         (rc = upload((void**)&s->d_slot_prim, h.slot_prim.data(), h.slot_prim.size() * 4)) ||
         (rc = upload((void**)&s->d_slot_label, h.slot_label.data(), h.slot_label.size() * 4))) {
@@ -929,7 +1102,7 @@ int lrc_scan_poses(lrc_scene* s, const double* poses16, uint64_t P, const double
     return st.download(*out, n);
 }
 
-static int ensure_tile_scratch(lrc_ctx* ctx, uint64_t ntiles);
+static int ensure_tile_scratch(lrc_ctx* ctx, lrc_ctx::TileScratch& sc, uint64_t ntiles);
 
 int lrc_compact_dev(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_compact_io* io,
                     void* stream) {
@@ -945,43 +1118,45 @@ int lrc_compact_dev(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_com
     const uint64_t ntiles = nseg * tps;
     const uint64_t nblocks = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
     if (nblocks > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: too many entries");
+    lrc_ctx::TileScratch& sc = ctx->compact_scratch;
     {
-        int rc_scratch = ensure_tile_scratch(ctx, ntiles);
+        int rc_scratch = ensure_tile_scratch(ctx, sc, ntiles);
         if (rc_scratch) return rc_scratch;
     }
     // the trace kernel can hand over its per-wave keep counts (lrc_hits.tile_count) when tiles line up
     const uint32_t* cnt = (io->tile_count && seg_len % 64 == 0) ? io->tile_count : nullptr;
     if (!cnt) {
         hipLaunchKernelGGL(compact_count_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, io->t, seg_len,
-                           tps, ntiles, ctx->d_tile_cnt);
-        cnt = ctx->d_tile_cnt;
+                           tps, ntiles, sc.d_tile_cnt);
+        cnt = sc.d_tile_cnt;
     }
     const uint64_t nsuper = (ntiles + 1023) / 1024;
-    hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(1024), 0, st, cnt, ctx->d_tile_off,
-                       ntiles, ctx->d_super_total);
-    hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)ctx->d_super_total,
-                       ctx->d_super_base, nsuper);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(1024), 0, st, cnt, ntiles, (uint64_t)0,
+                       sc.d_tile_off, ntiles, sc.d_super_total);
+    hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)sc.d_super_total,
+                       sc.d_super_base, nsuper);
     // the scatter grid must also cover the threads that write the per-segment counts (one per segment)
     const uint64_t need = io->counts ? (nseg + kBlock - 1) / kBlock : 0;
     const uint64_t grid = nblocks > need ? nblocks : need;
     hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, st, *io, seg_len, tps,
-                       ntiles, nseg, (const uint32_t*)ctx->d_tile_off, (const uint64_t*)ctx->d_super_base);
+                       ntiles, nseg, (const uint32_t*)sc.d_tile_off, (const uint64_t*)sc.d_super_base);
     LRC_HIP(hipGetLastError());
     return LRC_OK;
 }
 
-static int ensure_tile_scratch(lrc_ctx* ctx, uint64_t ntiles) {
-    if (ctx->tile_cap >= ntiles + 1) return LRC_OK;
-    if (ctx->d_tile_off) { (void)hipFree(ctx->d_tile_off); ctx->d_tile_off = nullptr; }
-    if (ctx->d_tile_cnt) { (void)hipFree(ctx->d_tile_cnt); ctx->d_tile_cnt = nullptr; }
-    if (ctx->d_super_total) { (void)hipFree(ctx->d_super_total); ctx->d_super_total = nullptr; }
-    if (ctx->d_super_base) { (void)hipFree(ctx->d_super_base); ctx->d_super_base = nullptr; }
-    ctx->tile_cap = 0;
-    LRC_HIP(hipMalloc((void**)&ctx->d_tile_off, (ntiles + 1) * 4));
-    LRC_HIP(hipMalloc((void**)&ctx->d_tile_cnt, (ntiles + 1) * 4));
-    LRC_HIP(hipMalloc((void**)&ctx->d_super_total, ((ntiles + 1023) / 1024 + 1) * 4));
-    LRC_HIP(hipMalloc((void**)&ctx->d_super_base, ((ntiles + 1023) / 1024 + 1) * 8));
-    ctx->tile_cap = ntiles + 1;
+static int ensure_tile_scratch(lrc_ctx* ctx, lrc_ctx::TileScratch& sc, uint64_t ntiles) {
+    (void)ctx;
+    if (sc.tile_cap >= ntiles + 1) return LRC_OK;
+    if (sc.d_tile_off) { (void)hipFree(sc.d_tile_off); sc.d_tile_off = nullptr; }
+    if (sc.d_tile_cnt) { (void)hipFree(sc.d_tile_cnt); sc.d_tile_cnt = nullptr; }
+    if (sc.d_super_total) { (void)hipFree(sc.d_super_total); sc.d_super_total = nullptr; }
+    if (sc.d_super_base) { (void)hipFree(sc.d_super_base); sc.d_super_base = nullptr; }
+    sc.tile_cap = 0;
+    LRC_HIP(hipMalloc((void**)&sc.d_tile_off, (ntiles + 1) * 4));
+    LRC_HIP(hipMalloc((void**)&sc.d_tile_cnt, (ntiles + 1) * 4));
+    LRC_HIP(hipMalloc((void**)&sc.d_super_total, ((ntiles + 1023) / 1024 + 1) * 4));
+    LRC_HIP(hipMalloc((void**)&sc.d_super_base, ((ntiles + 1023) / 1024 + 1) * 8));
+    sc.tile_cap = ntiles + 1;
     return LRC_OK;
 }
 
@@ -997,20 +1172,102 @@ int lrc_cloud_from_ranges_dev(lrc_ctx* ctx, const double* d_poses16, uint64_t P,
     const uint64_t tps = (N + 63) / 64, ntiles = P * tps;
     const uint64_t nblocks = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
     if (nblocks > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "lrc_cloud_from_ranges_dev: too many entries");
-    int rc = ensure_tile_scratch(ctx, ntiles);
+    lrc_ctx::TileScratch& sc = ctx->cloud_scratch;
+    int rc = ensure_tile_scratch(ctx, sc, ntiles);
     if (rc) return rc;
     const uint64_t nsuper = (ntiles + 1023) / 1024;
     hipLaunchKernelGGL(cloud_count_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, (const uint2*)d_t_label, N,
-                       tps, ntiles, ctx->d_tile_cnt);
+                       tps, ntiles, sc.d_tile_cnt);
     hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(1024), 0, st,
-                       (const uint32_t*)ctx->d_tile_cnt, ctx->d_tile_off, ntiles, ctx->d_super_total);
-    hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)ctx->d_super_total,
-                       ctx->d_super_base, nsuper);
+                       (const uint32_t*)sc.d_tile_cnt, ntiles, (uint64_t)0, sc.d_tile_off, ntiles, sc.d_super_total);
+    hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)sc.d_super_total,
+                       sc.d_super_base, nsuper);
     const uint64_t need = d_counts ? (P + kBlock - 1) / kBlock : 0;
     const uint64_t grid = nblocks > need ? nblocks : need;
     hipLaunchKernelGGL(cloud_scatter_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, st, d_poses16, d_dirs3,
-                       (const uint2*)d_t_label, N, tps, ntiles, P, (const uint32_t*)ctx->d_tile_off,
-                       (const uint64_t*)ctx->d_super_base, (float4*)d_out_xyzl, d_counts);
+                       (const uint2*)d_t_label, N, tps, ntiles, P, (const uint32_t*)sc.d_tile_off,
+                       (const uint64_t*)sc.d_super_base, (float4*)d_out_xyzl, d_counts);
+    LRC_HIP(hipGetLastError());
+    return LRC_OK;
+}
+
+// Checks the arguments of a rebuild from triangle ids, enqueues its preparation on `st` (tile offsets from the senders'
+// counts or from a counting pass, transposed direction table) and fills the kernel argument block.
+static int prepare_rebuild(lrc_scene* s, const char* who, const double* d_poses16, uint64_t P, const double* d_dirs3,
+                           uint64_t N, const uint32_t* d_prim, const uint32_t* d_tile_count, uint64_t poses_per_slab,
+                           uint64_t slab_stride_bytes, float* d_out_xyzl, uint64_t* d_counts, hipStream_t st,
+                           RebuildParams* q) {
+    auto bad = [&](const char* msg) { return fail(LRC_ERR_INVALID_ARG, std::string(who) + ": " + msg); };
+    if (!d_poses16 || !d_dirs3 || !d_prim || !d_out_xyzl) return bad("NULL argument");
+    if (s->opts.range_noise)
+        return bad("a scan with range noise cannot be rebuilt from triangle ids; gather (t,label) pairs "
+                   "(lrc_cloud_from_ranges_dev)");
+    const uint64_t tps = (N + 63) / 64, ntiles = P * tps;
+    if (poses_per_slab == 0 || poses_per_slab >= P) { poses_per_slab = P; slab_stride_bytes = 0; }
+    else if (slab_stride_bytes % 4 || slab_stride_bytes < poses_per_slab * N * 4)
+        return bad("slab stride smaller than a slab or not a multiple of 4");
+    if (d_tile_count && N % 64) return bad("tile counts need rays_per_pose % 64 == 0");
+    if (ntiles > 0x7FFFFFFFull || N > 0x7FFFFFFFull) return bad("too many entries");
+    lrc_ctx* ctx = s->ctx;
+    lrc_ctx::TileScratch& sc = ctx->cloud_scratch;
+    int rc = ensure_tile_scratch(ctx, sc, ntiles);
+    if (rc) return rc;
+    if (sc.dirs_cap < N) {
+        if (sc.d_dirs_soa) { (void)hipFree(sc.d_dirs_soa); sc.d_dirs_soa = nullptr; }
+        sc.dirs_cap = 0;
+        LRC_HIP(hipMalloc((void**)&sc.d_dirs_soa, N * 24));
+        sc.dirs_cap = N;
+    }
+    const uint64_t stride = slab_stride_bytes / 4;
+    const uint64_t nsuper = (ntiles + 1023) / 1024;
+    if (d_tile_count) {
+        // the senders' trace kernels already counted (lrc_hits.tile_count travels in the slab): no counting pass
+        hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(1024), 0, st, d_tile_count,
+                           poses_per_slab * tps, stride, sc.d_tile_off, ntiles, sc.d_super_total);
+    } else {
+        const uint64_t nblocks = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+        hipLaunchKernelGGL(prim_count_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, d_prim, poses_per_slab,
+                           stride, N, tps, ntiles, sc.d_tile_cnt);
+        hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(1024), 0, st,
+                           (const uint32_t*)sc.d_tile_cnt, ntiles, (uint64_t)0, sc.d_tile_off, ntiles,
+                           sc.d_super_total);
+    }
+    hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)sc.d_super_total,
+                       sc.d_super_base, nsuper);
+    hipLaunchKernelGGL(dirs_transpose_kernel, dim3((uint32_t)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       d_dirs3, (uint32_t)N, sc.d_dirs_soa);
+    q->poses16 = d_poses16;
+    q->dirs_soa = sc.d_dirs_soa;
+    q->prims = d_prim;
+    q->pps = (uint32_t)poses_per_slab;
+    q->stride = stride;
+    q->seg_len = (uint32_t)N;
+    q->tps = (uint32_t)tps;
+    q->ntiles = (uint32_t)ntiles;
+    q->nseg = (uint32_t)P;
+    q->plane = s->d_prim_plane;
+    q->num_prims = (uint32_t)s->info.num_triangles;
+    q->tile_off = sc.d_tile_off;
+    q->super_base = sc.d_super_base;
+    q->out_xyzl = (float4*)d_out_xyzl;
+    q->counts = d_counts;
+    return LRC_OK;
+}
+
+int lrc_cloud_from_prims_dev(lrc_scene* s, const double* d_poses16, uint64_t P, const double* d_dirs3, uint64_t N,
+                             const uint32_t* d_prim, const uint32_t* d_tile_count, uint64_t poses_per_slab,
+                             uint64_t slab_stride_bytes, float* d_out_xyzl, uint64_t* d_counts, void* stream) {
+    if (!s) return fail(LRC_ERR_INVALID_ARG, "lrc_cloud_from_prims_dev: scene is NULL");
+    if (P == 0 || N == 0) return LRC_OK;
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    RebuildParams q{};
+    int rc = prepare_rebuild(s, "lrc_cloud_from_prims_dev", d_poses16, P, d_dirs3, N, d_prim, d_tile_count,
+                             poses_per_slab, slab_stride_bytes, d_out_xyzl, d_counts, st, &q);
+    if (rc) return rc;
+    constexpr int kR = LRC_REBUILD_R;
+    const uint64_t wblocks = (((uint64_t)q.ntiles + kR - 1) / kR + kBlock / 64 - 1) / (kBlock / 64);
+    hipLaunchKernelGGL(prim_scatter_kernel<kR>, dim3((uint32_t)(wblocks ? wblocks : 1)), dim3(kBlock), 0, st, q);
     LRC_HIP(hipGetLastError());
     return LRC_OK;
 }

@@ -27,7 +27,7 @@ SYMBOLS = (
     "lrc_scene_get_counters", "lrc_scene_set_options", "lrc_scene_get_occupancy",
     "lrc_cast", "lrc_cast_dev", "lrc_cast_segments", "lrc_cast_segments_dev",
     "lrc_scan_poses", "lrc_scan_poses_dev",
-    "lrc_compact", "lrc_compact_dev", "lrc_cloud_from_ranges_dev",
+    "lrc_compact", "lrc_compact_dev", "lrc_cloud_from_ranges_dev", "lrc_cloud_from_prims_dev",
     "lrc_nn_create", "lrc_nn_destroy", "lrc_nn_query", "lrc_nn_query_dev",
     "lrc_min_distances", "lrc_rbf_kernel_sum",
     "lrc_occ_create", "lrc_occ_destroy", "lrc_occ_query",
@@ -108,6 +108,7 @@ def load():
         "lrc_nn_query": [vp, vp, u64, vp, vp],
         "lrc_nn_query_dev": [vp, vp, u64, vp, vp, vp],
         "lrc_cloud_from_ranges_dev": [vp, vp, u64, vp, u64, vp, vp, vp, vp],
+        "lrc_cloud_from_prims_dev": [vp, vp, u64, vp, u64, vp, vp, u64, u64, vp, vp, vp],
         "lrc_compact": [vp, u64, u64, C.POINTER(LrcCompactIO), C.POINTER(u64)],
         "lrc_compact_dev": [vp, u64, u64, C.POINTER(LrcCompactIO), vp],
     }

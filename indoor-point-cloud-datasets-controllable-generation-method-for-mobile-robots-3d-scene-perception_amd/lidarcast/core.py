@@ -290,6 +290,18 @@ class Scene:
                                            C.byref(hits.struct), C.c_void_p(int(stream))),
               "lrc_scan_poses_dev")
 
+    def cloud_from_prims_dev(self, poses_t, dirs_t, prim_t, out_rows_t, counts_t=None, tile_count_t=None,
+                             poses_per_slab=0, slab_stride_bytes=0, stream=0):
+        """Rebuild the compacted (x, y, z, label) rows of a pose-batched scan from its 4-byte triangle ids
+        (lrc_hits.prim), in place over the gathered send slabs of several ranks (lrc_cloud_from_prims_dev)."""
+        check(self._lib.lrc_cloud_from_prims_dev(
+            self._h, C.c_void_p(poses_t.data_ptr()), poses_t.shape[0], C.c_void_p(dirs_t.data_ptr()),
+            dirs_t.shape[0], C.c_void_p(prim_t.data_ptr()),
+            None if tile_count_t is None else C.c_void_p(tile_count_t.data_ptr()),
+            int(poses_per_slab), int(slab_stride_bytes), C.c_void_p(out_rows_t.data_ptr()),
+            None if counts_t is None else C.c_void_p(counts_t.data_ptr()), C.c_void_p(int(stream))),
+            "lrc_cloud_from_prims_dev")
+
 
 class NearestIndex:
     """Exact 1-NN into an annotated cloud on the GPU (reference: sklearn ball_tree query,

@@ -2,9 +2,11 @@
 
 The scan shards embarrassingly: waypoints are independent (reference loop, s3dis_simulator.py:254-288,
 carries no state between iterations except the frame order).  Each rank scans a contiguous block of
-poses against its own replica of the scene; one all-gather of the fixed-size slab of locally compacted
-16-byte rows (x, y, z, label bits) -- RCCL over xGMI on GPUs, gloo in the CPU tests -- assembles the
-scene point cloud in exactly the order of ``np.vstack(frames)`` (containers/s3dis_sim_scene.py:326,362).
+poses against its own replica of the scene; one all-gather per scan -- RCCL over xGMI on GPUs, gloo in the CPU
+tests -- assembles the scene point cloud in exactly the order of ``np.vstack(frames)``
+(containers/s3dis_sim_scene.py:326,362).  Three payloads, all fixed-stride (RCCL has no all-gather-v):
+``PrimGather`` 4-byte triangle ids (the pose-batched scan; points rebuilt on the receiver), ``RangeGather`` 8-byte
+(t, label) pairs (scans with range noise), ``CloudGather`` locally compacted 16-byte rows (host-generated rays).
 """
 import numpy as np
 
@@ -90,6 +92,63 @@ class RangeGather:
         if self.work is not None:
             self.work.wait()
             self.work = None
+
+
+class PrimGather:
+    """The all-gather of the pose-batched scan at 4 bytes per ray: the hit triangle's row (lrc_hits.prim).
+
+    A closest hit is a pure function of (pose, direction, triangle) and every rank holds the scene replica, the
+    poses and the direction table, so the receiver recomputes t -- with the scan's own ray/triangle test, bit for
+    bit -- and from it the point and the triangle's labels (lrc_cloud_from_prims_dev).  ``slab`` is the rank's send
+    buffer: ``prim`` (poses_local * rays_per_pose) int32, written by the trace kernel itself (lrc_hits.prim points
+    here), followed by ``tile_count`` (one int32 per 64 rays, lrc_hits.tile_count points here) so the receiver's
+    rebuild needs no counting pass, padded to 16 bytes.  ``all_slabs`` receives every rank's slab in rank order =
+    global pose order (ranks own contiguous pose blocks of ``poses_local`` poses; a rank with fewer poses pads with
+    -1 ids).  One collective per scan, half the bytes of RangeGather on the xGMI links."""
+
+    def __init__(self, poses_local, rays_per_pose, dist, device, world=None):
+        import torch
+        self.dist = dist
+        self.world = dist.get_world_size() if world is None else int(world)
+        self.poses_local, self.rays_per_pose = int(poses_local), int(rays_per_pose)
+        self.n = self.poses_local * self.rays_per_pose
+        self.fused_counts = self.rays_per_pose % 64 == 0
+        self.ntiles = self.poses_local * (self.rays_per_pose // 64) if self.fused_counts else 0
+        self.words = (self.n + self.ntiles + 3) // 4 * 4
+        self.stride_bytes = self.words * 4
+        self.slab = torch.full((self.words,), -1, dtype=torch.int32, device=device)
+        self.prim = self.slab[:self.n]
+        self.tile_count = self.slab[self.n:self.n + self.ntiles] if self.fused_counts else None
+        if self.fused_counts:
+            self.tile_count.zero_()
+        self.all_slabs = torch.empty((self.world * self.words,), dtype=torch.int32, device=device)
+        # ``world`` may exceed the process group (single-GPU diagnostics): the collective fills the leading slabs
+        self.recv = self.all_slabs[:dist.get_world_size() * self.words]
+        self.work = None
+
+    @property
+    def all_prims(self):
+        """Pointer view for lrc_cloud_from_prims_dev: entry 0 of slab 0."""
+        return self.all_slabs
+
+    @property
+    def all_tile_counts(self):
+        return self.all_slabs[self.n:] if self.fused_counts else None
+
+    def gather(self, async_op=False):
+        self.work = self.dist.all_gather_into_tensor(self.recv, self.slab, async_op=async_op)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+    def per_rank(self):
+        """Host view for tests: list of (prim (poses_local, rays_per_pose), tile_count or None) per rank."""
+        self.wait()
+        a = self.all_slabs.view(self.world, self.words).cpu().numpy()
+        return [(a[r, :self.n].reshape(self.poses_local, self.rays_per_pose),
+                 a[r, self.n:self.n + self.ntiles] if self.fused_counts else None) for r in range(self.world)]
 
 
 def gather_cloud(local_points, local_labels, local_counts, max_local, dist, device=None):

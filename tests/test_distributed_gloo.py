@@ -166,3 +166,93 @@ def test_pair_gather_rebuilds_the_vstack_cloud(world):
         assert p.exitcode == 0
     for rank, h, k in got:
         assert k == len(pts) and h == want, f"rank {rank} rebuilt a different cloud"
+
+
+def _prims_worker(rank, world, port, q):
+    """PrimGather protocol over gloo: each rank contributes the 4-byte hit-triangle ids of its pose block plus
+    the per-64-ray keep counts, in one fixed-size slab (a short rank pads with -1 ids / zero counts).  The cloud is
+    rebuilt from the gathered ids on every rank (stand-in for lrc_cloud_from_prims_dev, whose kernel the -m gpu
+    tests check against the local compaction: t is a function of (ray, triangle), here looked up from the oracle's
+    cast of the same ray after checking that it names the same triangle)."""
+    for p in (PKG, REPO, os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from lidarcast.distributed import PrimGather, shard_bounds
+    from lidar import create_lidar
+    from lidarcast import synth
+    from oracle.c_oracle import OracleMesh
+    from helpers import sensor_small
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    poses = _all_poses(7)                      # 7 poses: ragged blocks for world 2 (4+3) and 3 (3+2+2)
+    b = shard_bounds(len(poses), world)
+    ppr = int(max(b[1:] - b[:-1]))
+    mesh = synth.make_room(size=(3, 2.5, 2), num_boxes=2, seed=4, cell=0.1)
+    om = OracleMesh(mesh.vertices, mesh.triangles).build()
+    k = sensor_small(lines=3, width=64, max_range=1.6)
+    n_per = 192
+
+    def scan(m):
+        rays = create_lidar(k, m).get_rays()
+        t, prim = om.cast(rays)
+        d = rays[:, 3:] / np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+        pts = (rays[:, :3] + d * np.where(np.isfinite(t), t, 0)[:, None]).astype(np.float32)
+        keep = np.isfinite(t) & (np.linalg.norm(pts.astype(np.float64) - m[:3, 3], axis=1) < k.max_range)
+        return pts, prim, keep
+
+    g = PrimGather(ppr, n_per, dist, torch.device("cpu"))
+    assert g.fused_counts and g.words % 4 == 0 and g.stride_bytes == g.words * 4
+    mine = poses[b[rank]:b[rank + 1]]
+    for j, m in enumerate(mine):
+        _, prim, keep = scan(m)
+        g.prim[j * n_per:(j + 1) * n_per] = torch.from_numpy(np.where(keep, prim, 0xFFFFFFFF).astype(np.uint32)
+                                                              .view(np.int32))
+        g.tile_count[j * 3:(j + 1) * 3] = torch.from_numpy(keep.reshape(3, 64).sum(1).astype(np.int32))
+    g.gather(async_op=True)
+    rows, counts = [], []
+    for r, (prims, tcs) in enumerate(g.per_rank()):
+        for j in range(ppr):
+            gp = b[r] + j
+            ids = prims[j].view(np.uint32)
+            if j >= b[r + 1] - b[r]:                          # padding pose of a short rank
+                assert (ids == 0xFFFFFFFF).all() and (tcs[j * 3:(j + 1) * 3] == 0).all()
+                continue
+            pts, prim, keep = scan(poses[gp])
+            sent = ids != 0xFFFFFFFF
+            assert np.array_equal(sent, keep) and np.array_equal(ids[sent], prim[keep])
+            assert np.array_equal(tcs[j * 3:(j + 1) * 3], sent.reshape(3, 64).sum(1))
+            rows.append(pts[sent])
+            counts.append(int(sent.sum()))
+    cloud = np.concatenate(rows)
+    q.put((rank, hashlib.sha256(cloud.tobytes() + np.array(counts, np.int64).tobytes()).hexdigest(), len(cloud)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_triangle_id_gather_rebuilds_the_vstack_cloud(world):
+    from helpers import sensor_small
+    from lidar import create_lidar
+    from lidarcast import synth
+    from oracle import np_oracle
+    from oracle.c_oracle import OracleMesh
+    mesh = synth.make_room(size=(3, 2.5, 2), num_boxes=2, seed=4, cell=0.1)
+    om = OracleMesh(mesh.vertices, mesh.triangles).build()
+    k = sensor_small(lines=3, width=64, max_range=1.6)
+    frames = [np_oracle.lidar_intersect_mesh(om, create_lidar(k, m))[0] for m in _all_poses(7)]
+    want = hashlib.sha256(np.concatenate(frames).tobytes()
+                          + np.array([len(f) for f in frames], np.int64).tobytes()).hexdigest()
+    total = sum(len(f) for f in frames)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prims_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert total > 100
+    for rank, h, kk in got:
+        assert kk == total and h == want, f"rank {rank} rebuilt a different cloud"

@@ -427,6 +427,83 @@ def test_device_path_fused_tile_counts_and_packed_rows(ctx):
         assert np.array_equal(tc, pad.reshape(-1, 64).sum(1))
 
 
+def test_cloud_rebuilt_from_triangle_ids(ctx):
+    """What the multi-GPU all-gather moves is 4 bytes per ray, the hit triangle's row: the rows rebuilt from ids
+    alone (t recomputed by the same ray/triangle test) equal the local compaction bit for bit -- over one
+    contiguous array, and in place over per-rank send slabs (ids, then per-wave keep counts, then padding; a
+    short rank padded with invalid ids), with and without the senders' counts, for yawed poses too."""
+    import torch
+    import lidarcast
+    from lidarcast import synth
+    from lidarcast._capi import LrcCompactIO
+    from lidar import IndoorLidar
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=4, seed=5, cell=0.04)
+    scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    for lines, width, max_range in ((4, 256, 2.0), (3, 100, 20.0)):       # 1024 (tiles line up) and 300 rays per pose
+        k = sensor_small(lines=lines, width=width, max_range=max_range)
+        poses = np.stack([pose(1.0 + 0.5 * i, 1.5, 1.0, yaw=0.37 * i) for i in range(5)])
+        dirs = IndoorLidar(k, np.eye(4)).sensor_directions()
+        P, N = len(poses), len(dirs)
+        hits = lidarcast.DeviceHits(P * N, dev, want=("t", "prim", "point3", "sem", "ins", "tile_count"))
+        d_poses = torch.from_numpy(poses.reshape(P, 16)).to(dev)
+        d_dirs = torch.from_numpy(dirs).to(dev)
+        rows = torch.zeros((P * N, 4), dtype=torch.float32, device=dev)
+        counts = torch.zeros(P, dtype=torch.int64, device=dev)
+        io = LrcCompactIO()
+        io.t, io.point3, io.sem, io.ins = (hits[a].data_ptr() for a in ("t", "point3", "sem", "ins"))
+        io.tile_count, io.counts, io.out_xyzl = hits["tile_count"].data_ptr(), counts.data_ptr(), rows.data_ptr()
+        scene.scan_poses_dev(d_poses, d_dirs, hits, k.max_range, st)
+        ctx.compact_dev(P, N, io, st)
+        torch.cuda.synchronize()
+        K = int(counts.sum().item())
+        assert 0 < K and (K < P * N or max_range > 10)
+        # (1) one contiguous id array, counting pass in the rebuild
+        rows2, counts2 = torch.full_like(rows, 7.0), torch.zeros_like(counts)
+        scene.cloud_from_prims_dev(d_poses, d_dirs, hits["prim"], rows2, counts2, stream=st)
+        torch.cuda.synchronize()
+        assert torch.equal(counts2, counts)
+        assert torch.equal(rows2[:K].view(torch.int32), rows[:K].view(torch.int32))
+        # (2) three "ranks" of 2 poses each (the last one owns a single pose): slabs = ids | counts | padding
+        pps, nslab = 2, 3
+        tps = N // 64 if N % 64 == 0 else 0
+        words = (pps * N + pps * tps + 3) // 4 * 4 + 8               # + 8: a stride larger than the payload
+        slabs = torch.full((nslab * words,), -1, dtype=torch.int32, device=dev)
+        prim = hits["prim"].view(P, N)
+        tc = hits["tile_count"][:P * tps].view(P, tps) if tps else None
+        for r in range(nslab):
+            own = range(r * pps, min((r + 1) * pps, P))
+            for j, pi in enumerate(own):
+                slabs[r * words + j * N:r * words + (j + 1) * N] = prim[pi]
+                if tps:
+                    slabs[r * words + pps * N + j * tps:r * words + pps * N + (j + 1) * tps] = tc[pi]
+            if tps:
+                for j in range(len(own), pps):
+                    slabs[r * words + pps * N + j * tps:r * words + pps * N + (j + 1) * tps] = 0
+        padded = np.concatenate([poses, poses[:1]]).reshape(nslab * pps, 16)   # the padding pose is arbitrary
+        d_padded = torch.from_numpy(padded).to(dev)
+        for with_counts in ((True, False) if tps else (False,)):
+            rows3 = torch.full_like(rows, 7.0)
+            counts3 = torch.zeros(nslab * pps, dtype=torch.int64, device=dev)
+            scene.cloud_from_prims_dev(d_padded, d_dirs, slabs, rows3, counts3,
+                                       tile_count_t=slabs[pps * N:] if with_counts else None,
+                                       poses_per_slab=pps, slab_stride_bytes=words * 4, stream=st)
+            torch.cuda.synchronize()
+            assert torch.equal(counts3[:P], counts) and int(counts3[P:].sum().item()) == 0
+            assert torch.equal(rows3[:K].view(torch.int32), rows[:K].view(torch.int32))
+            assert bool((rows3[K:] == 7.0).all())
+    # argument checks: counts need aligned tiles; a range-noise scan cannot be rebuilt from ids
+    with pytest.raises(ValueError):
+        scene.cloud_from_prims_dev(d_poses, d_dirs, hits["prim"], rows2, counts2, tile_count_t=hits["tile_count"],
+                                   stream=st)
+    noise = torch.zeros(P * N, dtype=torch.float32, device=dev)
+    scene.set_options(range_noise=(noise.data_ptr(), noise.numel()))
+    with pytest.raises(ValueError):
+        scene.cloud_from_prims_dev(d_poses, d_dirs, hits["prim"], rows2, counts2, stream=st)
+    scene.reset_options()
+
+
 def test_full_size_c3_properties(ctx):
     """BASELINE config C3 at full size (64 poses x 65 536 rays, T = 605 328), device-resident path.
     Size-independent properties + four poses checked ray by ray against the oracle."""

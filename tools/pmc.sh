@@ -1,8 +1,11 @@
 #!/bin/bash
-# tools/pmc.sh <tag> -- rocprofv3 counter passes over a short bench.py run (GPU box only).
+# tools/pmc.sh <tag> [kernel-name-pattern] -- rocprofv3 counter passes over a short bench.py run (GPU box only).
+# PMC_ARGS overrides the bench.py arguments (e.g. "--dist-selftest --virtual-world 8 ..." for the rebuild kernel).
 # Counters are collected in their own runs (no tracing domains besides --kernel-trace), one group per pass.
 set -u
 TAG=${1:-pmc}
+PAT=${2:-trace_kernel}
+ARGS=${PMC_ARGS:---steps 3 --warmup 1 --no-cpu-baseline}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -17,7 +20,7 @@ for grp in \
   "FETCH_SIZE" \
   "WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" ; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 $R/bench.py $ARGS > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
-python3 $R/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+python3 $R/tools/pmc_summary.py $OUT $PAT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -59,6 +59,8 @@ for wc in (True, False):
     k = int(counts.sum().item())
     print(f"W={W} with_counts={wc}: {ms*1e3:.1f} us per rebuild of {W*n} entries ({k} rows), "
           f"{(W*n*4 + k*16)/ms/1e6:.0f} GB/s (ids in + rows out)", flush=True)
+k = int(counts.sum().item())
+print("checksum", int(cloud[:k].view(torch.int32).to(torch.int64).sum().item()), k, flush=True)
 # reference point: plain fill of the same output
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -83,6 +83,21 @@ class IndoorLidar:
             origins = np.expand_dims(c, axis=0).repeat(len(d64), axis=0).astype(np.float32)
         return np.concatenate([origins, world], axis=-1)
 
+    # the reference's generator entry points, same names and (origins, directions) float32 return
+    @staticmethod
+    def _gen_lidar_rays(pose, fov_up, fov_down, H, W):
+        """Uniform-elevation branch (lidar/indoor_lidar.py:56-91)."""
+        d32 = IndoorLidar.directions_uniform(fov_up, fov_down, H, W)
+        world = (pose[:3, :3] @ d32.T).T.astype(np.float32)
+        return np.tile(pose[:3, 3], (len(d32), 1)).astype(np.float32), world
+
+    @staticmethod
+    def _gen_lidar_rays_with_vertical_degrees(pose, vertical_degrees, W):
+        """Listed-elevation branch (lidar/indoor_lidar.py:94-131)."""
+        d64 = IndoorLidar.directions_from_vertical_degrees(vertical_degrees, W)
+        world = np.dot(d64, pose[:3, :3].T).astype(np.float32)
+        return np.expand_dims(pose[:3, 3], axis=0).repeat(len(d64), axis=0).astype(np.float32), world
+
     def get_total_rays(self) -> int:
         k = self.intrinsics
         if k.vertical_degrees is None:
@@ -146,6 +161,55 @@ class DualAxisLidar:
 
     def get_rays(self) -> np.ndarray:
         return self.get_multi_line_rays()
+
+    # -- single-line time-sampled generators (reference lidar/indoor_lidar.py:162-222, :298-340) -------------
+    def _rotate(self, d):
+        """Rows of d (n,3) float64 through the pose rotation, as the reference's per-ray ``R @ d``."""
+        R = self.pose[:3, :3]
+        return (d[:, 0:1] * R[:, 0][None, :] + d[:, 1:2] * R[:, 1][None, :]) + d[:, 2:3] * R[:, 2][None, :]
+
+    def get_rays_sequence(self, time_sequence: np.ndarray) -> np.ndarray:
+        """(N,6) float32 rays of scan line 0 at the given times.  The reference loops over the times and draws
+        two scalar normals per step (phi's, then theta's); one normal(size=2N) call consumes the stream alike."""
+        k = self.intrinsics
+        rnd = np.random if self.rng is None else self.rng
+        t = np.asarray(time_sequence, dtype=np.float64).reshape(-1)
+        phi, theta = k.swing_angles(t, 0)
+        if k.angle_noise_std > 0 and t.size:
+            z = rnd.normal(0, k.angle_noise_std, size=2 * t.size).reshape(t.size, 2)
+            phi, theta = phi + z[:, 0], theta + z[:, 1]
+        ct = np.cos(theta)
+        d = np.stack([ct * np.cos(phi), ct * np.sin(phi), np.sin(theta)], axis=-1)
+        rays = np.empty((t.size, 6), dtype=np.float32)
+        rays[:, :3] = self.pose[:3, 3].astype(np.float32)
+        rays[:, 3:] = self._rotate(d).astype(np.float32)
+        return rays
+
+    def get_rays_at_time(self, t: float) -> np.ndarray:
+        """(1,6) float32: the ray of scan line 0 at time t.  Unlike the sequence form the reference narrows the
+        sensor-frame direction to float32 BEFORE rotating it."""
+        phi, theta = self.intrinsics.calculate_angles_at_time(t, line_idx=0)
+        d32 = np.array([np.cos(theta) * np.cos(phi), np.cos(theta) * np.sin(phi), np.sin(theta)], dtype=np.float32)
+        world = self._rotate(d32.astype(np.float64)[None, :])[0].astype(np.float32)
+        return np.concatenate([self.pose[:3, 3].astype(np.float32), world]).reshape(1, 6)
+
+    def get_rays_frame(self, frame_duration: float = None) -> np.ndarray:
+        return self.get_rays_sequence(self.intrinsics.generate_time_sequence(frame_duration))
+
+    def get_spiral_scan_rays(self, num_points: int = None):
+        """(rays, timestamps): num_points samples spread over one scan_duration, end point included."""
+        k = self.intrinsics
+        if num_points is None:
+            num_points = int(k.point_rate * k.scan_duration)
+        stamps = np.linspace(0, k.scan_duration, num_points)
+        return self.get_rays_sequence(stamps), stamps
+
+    def add_noise_to_rays(self, rays: np.ndarray) -> np.ndarray:
+        """Dropout only: one uniform draw per ray from the global stream (lidar/indoor_lidar.py:354-370)."""
+        if self.intrinsics.dropout_probability > 0:
+            rnd = np.random if self.rng is None else self.rng
+            rays = rays[rnd.random(len(rays)) > self.intrinsics.dropout_probability]
+        return rays
 
     def get_total_rays(self) -> int:
         return int(self.intrinsics.point_rate * self.intrinsics.scan_duration)

@@ -1,11 +1,14 @@
 """Sensor parameter records (same names, fields and factory values as the reference).
 
 Reference: lidar/lidar_intrinsics.py:12-25 (base), :29-211 (dual axis), :215-389 (multi-line).
-Only what the scan path reads is kept: the parameter values, the factories and the three small
-accessors the simulator calls.  The reference's ``add_noise`` has no call site and
-is not reproduced.
+Parameter values, factories and accessors; plus the helpers the reference defines without ever calling them
+(``calculate_angles_at_time``, ``generate_time_sequence``, ``add_noise``: SURVEY.md F6), kept so that code written
+against the reference finds them -- they draw from the global numpy stream in the reference's order
+(tests/golden/make_lidar_api_golden.py).
 """
 import math
+
+import numpy as np
 from abc import ABC
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
@@ -69,6 +72,45 @@ class DualAxisLidarIntrinsics(LidarIntrinsics):
         keys = ("phi_0", "omega_phi", "scan_duration", "point_rate", "phi_range", "theta_range",
                 "swing_amplitude", "swing_frequency")
         return {k: getattr(self, k) for k in keys}
+
+    def swing_angles(self, t, line_idx: int = 0):
+        """Noise-free (phi, theta) at time(s) t for one scan line: azimuth turns at omega_phi (mod 2 pi), the
+        line's elevation nods around its base angle with a per-line phase, clipped to theta_range
+        (lidar_intrinsics.py:82-113 without the noise).  t may be an array."""
+        t = np.asarray(t, dtype=np.float64)
+        lo, hi = self.theta_range
+        L = self.num_vertical_lines
+        phi = (self.phi_0 + self.omega_phi * t) % (2 * np.pi)
+        base = np.linspace(hi, lo, L)[line_idx % L]
+        nod = self.swing_amplitude * np.sin(self.swing_frequency * t + line_idx * 2 * np.pi / L)
+        return phi, np.clip(base + nod, lo, hi)
+
+    def calculate_angles_at_time(self, t: float, line_idx: int = 0) -> tuple:
+        """(phi, theta) in radians at time t; with angle noise two scalar normals are drawn from the global numpy
+        stream, phi's first (lidar_intrinsics.py:82-113)."""
+        phi, theta = self.swing_angles(t, line_idx)
+        if self.angle_noise_std > 0:
+            phi = phi + np.random.normal(0, self.angle_noise_std)
+            theta = theta + np.random.normal(0, self.angle_noise_std)
+        return phi, theta
+
+    def generate_time_sequence(self, frame_duration: float = None) -> np.ndarray:
+        """Sample times of one output frame: int(point_rate * duration) steps of equal length from 0
+        (lidar_intrinsics.py:115-135)."""
+        span = self.frame_duration if frame_duration is None else frame_duration
+        n = int(self.point_rate * span)
+        return np.arange(0, span, span / n)
+
+    @classmethod
+    def create_custom_dual_axis(cls, phi_0: float = 0.0, theta_0: float = 15.0, omega_phi: float = 2.0 * math.pi,
+                                omega_theta: float = -0.1, point_rate: int = 420000, scan_duration: float = 1.0):
+        """The reference's factory passes three fields the record does not have (theta_0, omega_theta,
+        use_spiral_scan; lidar_intrinsics.py:188-211), so calling it raises TypeError there; it does here too,
+        the same way."""
+        fields = dict(phi_0=phi_0, theta_0=theta_0 * _DEG, omega_phi=omega_phi, omega_theta=omega_theta,
+                      scan_duration=scan_duration, point_rate=point_rate, use_spiral_scan=True, frame_duration=0.1,
+                      fov_up=15.0, fov_down=20.0, vertical_res=1, horizontal_res=1, max_range=25.0)
+        return cls(**fields)
 
 
 @dataclass
@@ -138,3 +180,17 @@ class Indoor8LineLidarIntrinsics(LidarIntrinsics):
 
     def get_range_limits(self) -> tuple:
         return (self.min_range, self.max_range)
+
+    def add_noise(self, points, ranges, angles, intensities) -> tuple:
+        """Measurement noise model the reference declares but never calls (lidar_intrinsics.py:364-389): additive
+        normal noise on ranges (range_noise_std), angles (angle_noise_std given in DEGREES) and intensities
+        (clipped to [0, 1]), then one uniform draw per point for the dropout.  Global numpy stream, in that order.
+        With dropout off the three noisy arrays keep their length and ``points`` is returned as is."""
+        ranges, angles, intensities = np.asarray(ranges), np.asarray(angles), np.asarray(intensities)
+        r = ranges + np.random.normal(0, self.range_noise_std, ranges.shape)
+        a = angles + np.random.normal(0, np.deg2rad(self.angle_noise_std), angles.shape)
+        i = np.clip(intensities + np.random.normal(0, self.intensity_noise_std, intensities.shape), 0, 1)
+        if self.dropout_probability > 0:
+            keep = np.random.random(len(points)) > self.dropout_probability
+            return points[keep], r[keep], a[keep], i[keep]
+        return points, r, a, i

@@ -1,8 +1,9 @@
 """Per-pose scan record the engine output is poured into (reference: containers/s3dis_sim_frame.py:12-40, :84-101).
 
-Only the parts the scan path touches: the quality record, the frame with its length check, and the
-accessors the scene statistics read.  Per-ray hit attributes the HIP engine writes back (semantic /
-instance label per point) ride along as optional arrays.
+The quality record, the incident-angle record, and the frame with its length check, accessors, filters and
+dictionary round trip -- same names and results as the reference (tests/golden/make_containers_golden.py runs the
+reference's own classes).  Per-ray hit attributes the HIP engine writes back (semantic / instance label per point)
+ride along as optional arrays and follow the points through the filters.
 """
 from dataclasses import asdict, dataclass
 from typing import Any, Dict, Optional
@@ -26,6 +27,37 @@ class ScanQuality:
     @classmethod
     def from_dict(cls, quality_dict: Dict[str, Any]) -> "ScanQuality":
         return cls(**quality_dict)
+
+
+@dataclass
+class IncidentAngles:
+    """Incident angles of a scan with the optional surface normals / ray directions they came from
+    (reference: containers/s3dis_sim_frame.py:43-82)."""
+    angles: np.ndarray
+    surface_normals: Optional[np.ndarray] = None
+    ray_directions: Optional[np.ndarray] = None
+
+    def get_mean_angle(self) -> float:
+        return np.mean(self.angles)
+
+    def get_std_angle(self) -> float:
+        return np.std(self.angles)
+
+    def get_angle_distribution(self, num_bins: int = 20) -> tuple:
+        return np.histogram(self.angles, bins=num_bins)
+
+    def to_dict(self) -> Dict[str, Any]:
+        def lst(a):
+            return a.tolist() if a is not None else None
+        return {"angles": self.angles.tolist(), "surface_normals": lst(self.surface_normals),
+                "ray_directions": lst(self.ray_directions)}
+
+    @classmethod
+    def from_dict(cls, angles_dict: Dict[str, Any]) -> "IncidentAngles":
+        def arr(key):      # an empty list counts as absent, as in the reference
+            return np.array(angles_dict[key]) if angles_dict[key] else None
+        return cls(angles=np.array(angles_dict["angles"]), surface_normals=arr("surface_normals"),
+                   ray_directions=arr("ray_directions"))
 
 
 class S3DISSimFrame:
@@ -77,10 +109,50 @@ class S3DISSimFrame:
         return {"x_min": float(lo[0]), "x_max": float(hi[0]), "y_min": float(lo[1]),
                 "y_max": float(hi[1]), "z_min": float(lo[2]), "z_max": float(hi[2])}
 
+    def get_point_cloud_center(self) -> np.ndarray:
+        return np.mean(self.points, axis=0) if len(self.points) else np.array([0, 0, 0])
+
+    def get_point_cloud_std(self) -> np.ndarray:
+        return np.std(self.points, axis=0) if len(self.points) else np.array([0, 0, 0])
+
+    def _subset(self, mask) -> "S3DISSimFrame":
+        """The frame restricted to mask, quality re-derived as the reference's two filters do (:157-205): coverage
+        and density scale with the kept fraction, angle statistics from the kept angles, ranges from the WORLD
+        origin; an empty source frame divides by zero there and here."""
+        pts, ang = self.points[mask], self.incident_angles[mask]
+        frac = len(pts) / len(self.points)
+        rng = np.linalg.norm(pts, axis=1) if len(pts) > 0 else None
+        q = ScanQuality(
+            coverage_ratio=self.scan_quality.coverage_ratio * frac, num_points=len(pts),
+            incident_angle_mean=np.mean(ang) if len(ang) > 0 else 0,
+            incident_angle_std=np.std(ang) if len(ang) > 0 else 0,
+            scan_density=self.scan_quality.scan_density * frac,
+            range_mean=np.mean(rng) if rng is not None else 0, range_std=np.std(rng) if rng is not None else 0)
+        return S3DISSimFrame(frame_index=self.frame_index, points=pts, incident_angles=ang, scan_quality=q,
+                             frame_metadata=self.frame_metadata.copy(),
+                             semantic_labels=None if self.semantic_labels is None else self.semantic_labels[mask],
+                             instance_labels=None if self.instance_labels is None else self.instance_labels[mask])
+
+    def filter_points_by_angle(self, min_angle: float = 0, max_angle: float = np.pi / 2) -> "S3DISSimFrame":
+        """Points whose incident angle lies in [min_angle, max_angle] (bounds in the unit the angles are stored in)."""
+        return self._subset((self.incident_angles >= min_angle) & (self.incident_angles <= max_angle))
+
+    def filter_points_by_range(self, min_range: float = 0, max_range: float = float("inf")) -> "S3DISSimFrame":
+        """Points whose distance from the world origin lies in [min_range, max_range]."""
+        r = np.linalg.norm(self.points, axis=1)
+        return self._subset((r >= min_range) & (r <= max_range))
+
     def to_dict(self) -> Dict[str, Any]:
         return {"frame_index": self.frame_index, "points": self.points.tolist(),
                 "incident_angles": self.incident_angles.tolist(),
                 "scan_quality": self.scan_quality.to_dict(), "frame_metadata": self.frame_metadata}
+
+    @classmethod
+    def from_dict(cls, frame_dict: Dict[str, Any]) -> "S3DISSimFrame":
+        return cls(frame_index=frame_dict["frame_index"], points=np.array(frame_dict["points"]),
+                   incident_angles=np.array(frame_dict["incident_angles"]),
+                   scan_quality=ScanQuality.from_dict(frame_dict["scan_quality"]),
+                   frame_metadata=frame_dict.get("frame_metadata", {}))
 
     def __repr__(self) -> str:
         return (f"S3DISSimFrame(index={self.frame_index}, points={self.get_num_points()}, "

@@ -1,13 +1,22 @@
-"""Scene assembly: frames -> statistics -> combined cloud -> PLY
-(reference: containers/s3dis_sim_scene.py:150, :228-247, :306-377, :614-641).
+"""Scene assembly: frames -> statistics -> combined cloud -> result files
+(reference: containers/s3dis_sim_scene.py; class and method names, file names and file contents follow it --
+tests/golden/make_containers_golden.py runs the reference's own classes for the fixtures).
 
 Differences from the reference, all on purpose:
   * labels come from the hit triangles (written back by the trace kernel) when the frames carry
     them, instead of a 1-NN query against the raw annotated cloud at export time;
-    without labels the reference's defaults apply (grey 0.5 -> 127, labels 0, :575-584);
+    without labels the reference's defaults apply (grey 0.5 -> 127, labels 0, :575-584); with an annotated
+    cloud attached (``set_annotated_cloud``) the reference's 1-NN assignment runs, on the GPU;
   * the labelled PLY is written with one structured-array ``tofile`` instead of a per-point
-    ``struct.pack`` loop; header and record layout are byte-identical (:619-641).
+    ``struct.pack`` loop; header and record layout are byte-identical (:619-641);
+  * ``combined_pointcloud.ply`` is written by this package's own PLY writer (the reference hands it to Open3D);
+  * the S3DIS annotation file loaders are out of scope: the ``_load_s3dis_*`` hooks try the
+    reference's ``s3dis_annotation_loader`` module if the caller has it on the path and otherwise report "no data",
+    which is exactly what the reference's own try/except does when the module is missing.
 """
+import json
+import os
+import pickle
 from dataclasses import asdict, dataclass
 from pathlib import Path
 from typing import Any, Dict, List, Optional
@@ -15,6 +24,19 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 
 from .s3dis_sim_frame import S3DISSimFrame
+
+
+class NumpyEncoder(json.JSONEncoder):
+    """numpy scalars and arrays as plain JSON numbers / lists."""
+
+    def default(self, obj):
+        if isinstance(obj, np.integer):
+            return int(obj)
+        if isinstance(obj, np.floating):
+            return float(obj)
+        if isinstance(obj, np.ndarray):
+            return obj.tolist()
+        return super().default(obj)
 
 
 @dataclass
@@ -30,6 +52,69 @@ class SimulationStats:
 
     def to_dict(self) -> Dict[str, Any]:
         return asdict(self)
+
+
+class ResultExporter:
+    """Writes frames, statistics and the summary below one output directory (reference :57-130: same file names,
+    same text)."""
+
+    _STAT_LINES = (("Total frames", "total_frames", ""), ("Total points", "total_points", ""),
+                   ("Average coverage", "average_coverage", ".3f"),
+                   ("Average scan density", "average_scan_density", ".3f"),
+                   ("Average incident angle", "average_incident_angle", ".3f"),
+                   ("Average range", "average_range", ".3f"))
+
+    def __init__(self, output_dir: Path):
+        self.output_dir = Path(output_dir)
+        self.output_dir.mkdir(parents=True, exist_ok=True)
+
+    def export_frames(self, frames: List[S3DISSimFrame], format: str = "pkl"):
+        if format not in ("pkl", "json"):
+            raise ValueError(f"Unsupported format: {format}")
+        frames_dir = self.output_dir / "frames"
+        frames_dir.mkdir(exist_ok=True)
+        for frame in frames:
+            path = frames_dir / f"frame_{frame.frame_index:04d}.{format}"
+            if format == "pkl":
+                with open(path, "wb") as f:
+                    pickle.dump(frame.to_dict(), f)
+            else:
+                with open(path, "w") as f:
+                    json.dump(frame.to_dict(), f, indent=2, cls=NumpyEncoder)
+
+    def export_statistics(self, stats: SimulationStats, format: str = "json"):
+        if format == "json":
+            with open(self.output_dir / "simulation_statistics.json", "w") as f:
+                json.dump(stats.to_dict(), f, indent=2, cls=NumpyEncoder)
+        elif format == "txt":
+            lines = ["Simulation Statistics", "=" * 50]
+            lines += [f"{label}: {format_spec(getattr(stats, attr), spec)}" for label, attr, spec in self._STAT_LINES]
+            lines += [f"Simulation time: {stats.simulation_time:.3f}s",
+                      f"Frames per second: {stats.frames_per_second:.3f} FPS"]
+            with open(self.output_dir / "simulation_statistics.txt", "w") as f:
+                f.write("\n".join(lines) + "\n")
+        else:
+            raise ValueError(f"Unsupported format: {format}")
+
+    def export_summary(self, sim_scene: "S3DISSimScene", format: str = "json"):
+        if format != "json":
+            raise ValueError(f"Unsupported format: {format}")
+        summary = {
+            "scene_name": sim_scene.scene_name,
+            "simulation_config": sim_scene.simulation_config,
+            "statistics": sim_scene.statistics.to_dict(),
+            "frame_summary": {
+                "frame_indices": [f.frame_index for f in sim_scene.frames],
+                "point_counts": [f.get_num_points() for f in sim_scene.frames],
+                "coverage_ratios": [f.get_coverage_ratio() for f in sim_scene.frames],
+            },
+        }
+        with open(self.output_dir / "simulation_summary.json", "w") as f:
+            json.dump(summary, f, indent=2, cls=NumpyEncoder)
+
+
+def format_spec(value, spec):
+    return format(value, spec) if spec else str(value)
 
 
 PLY_HEADER = (b"ply\nformat binary_little_endian 1.0\nelement vertex %d\n"
@@ -74,8 +159,10 @@ class S3DISSimScene:
         self.simulation_config = simulation_config or {}
         self.frames: List[S3DISSimFrame] = []
         self.statistics: Optional[SimulationStats] = None
+        self.exporter: Optional[ResultExporter] = None
         self.mesh = mesh
         self.s3dis_data_root, self.area, self.room = s3dis_data_root, area, room
+        self._s3dis_cache = None      # the reference's cache slot (dict of the four annotated arrays)
         self._annotated = None        # (points f64 (M,3), colors (M,3) in 0..1, sem (M,), ins (M,))
         self._nn = None
 
@@ -89,7 +176,7 @@ class S3DISSimScene:
         return sum(f.get_num_points() for f in self.frames)
 
     def _mean(self, getter) -> float:
-        return float(np.mean([getter(f) for f in self.frames])) if self.frames else 0.0
+        return np.mean([getter(f) for f in self.frames]) if self.frames else 0.0
 
     def get_average_coverage(self) -> float:
         return self._mean(S3DISSimFrame.get_coverage_ratio)
@@ -102,6 +189,29 @@ class S3DISSimScene:
 
     def get_average_range(self) -> float:
         return self._mean(S3DISSimFrame.get_mean_range)
+
+    def get_frame_statistics(self) -> Dict[str, List[float]]:
+        """Per-frame series (empty dict without frames)."""
+        if not self.frames:
+            return {}
+        series = (("frame_indices", lambda f: f.frame_index), ("point_counts", S3DISSimFrame.get_num_points),
+                  ("coverage_ratios", S3DISSimFrame.get_coverage_ratio),
+                  ("scan_densities", S3DISSimFrame.get_scan_density),
+                  ("incident_angles", S3DISSimFrame.get_mean_incident_angle),
+                  ("ranges", S3DISSimFrame.get_mean_range))
+        return {name: [get(f) for f in self.frames] for name, get in series}
+
+    def get_quality_distribution(self) -> Dict[str, Any]:
+        """mean / std / min / max of the coverage, point-count and incident-angle series."""
+        if not self.frames:
+            return {}
+        per_frame = self.get_frame_statistics()
+
+        def four(v):
+            return {"mean": np.mean(v), "std": np.std(v), "min": np.min(v), "max": np.max(v)}
+        return {"coverage_distribution": four(per_frame["coverage_ratios"]),
+                "point_count_distribution": four(per_frame["point_counts"]),
+                "incident_angle_distribution": four(per_frame["incident_angles"])}
 
     def compute_statistics(self, simulation_time: float = 0.0):
         n = self.get_total_frames()
@@ -149,6 +259,14 @@ class S3DISSimScene:
     def _get_colors_and_labels_from_s3dis(self, points: np.ndarray):
         """Nearest annotated point per hit point -> (colors, semantic, instance); defaults without a cloud.
         Same contract as the reference method of this name (:379-427); the ball-tree query is the GPU 1-NN."""
+        if (self._annotated is None and self._s3dis_cache is None and self.s3dis_data_root and self.area
+                and self.room):
+            # the reference's lazy load through the caller's annotation loader (:392-409), tried once
+            self._s3dis_cache = {}
+            pts, cols, sem, ins = self._load_s3dis_annotations_with_colors()
+            if pts is not None and len(pts) > 0:
+                self.set_annotated_cloud(pts, cols, sem, ins)
+                self._s3dis_cache = {"points": pts, "colors": cols, "labels": sem, "instances": ins}
         if self._annotated is None or len(points) == 0:
             return self._get_default_colors_and_labels(len(points))
         if self._nn is None:
@@ -159,27 +277,200 @@ class S3DISSimScene:
         _, colors, sem, ins = self._annotated
         return colors[idx], sem[idx], ins[idx]
 
-    def save_results(self, output_dir, formats=("txt",)):
-        out = Path(output_dir)
-        out.mkdir(parents=True, exist_ok=True)
-        if self.statistics is None:
-            self.compute_statistics()
-        if "txt" in formats:
-            with open(out / "simulation_statistics.txt", "w", encoding="utf-8") as f:
-                for k, v in self.statistics.to_dict().items():
-                    f.write(f"{k}: {v}\n")
+    # ---- result files (reference :249-337, :339-377, :614-641) ---------------------------------------------
+    def save_results(self, output_dir: Path, formats: List[str] = ["pkl", "txt"]):
+        """Statistics (json and/or txt), summary (json, else the plain-text one), combined_pointcloud.ply and
+        combined_pointcloud_with_label.ply below output_dir.  As in the reference the statistics are recomputed
+        here with simulation_time 0, and per-frame files are not written."""
+        output_dir = Path(output_dir)
+        self.exporter = ResultExporter(output_dir)
+        self.compute_statistics()
+        for fmt in formats:
+            if fmt in ("json", "txt"):
+                self.exporter.export_statistics(self.statistics, fmt)
+        if "json" in formats:
+            self.exporter.export_summary(self, "json")
+        elif "txt" in formats:
+            self._save_simple_summary(output_dir)
+        self._export_combined_pointcloud(output_dir)
+        self._export_combined_pointcloud_with_labels(output_dir)
+
+    def _save_simple_summary(self, output_dir: Path):
+        lines = ["S3DIS Simulation Results Summary", "=" * 50, "",
+                 f"Scene name: {self.scene_name}",
+                 f"Total frames: {len(self.frames)}",
+                 f"Total points: {self.get_total_points():,}",
+                 f"Average coverage: {self.get_average_coverage():.3f}",
+                 f"Average scan density: {self.get_average_scan_density():.3f}",
+                 f"Average incident angle: {self.get_average_incident_angle():.1f}\u00b0",
+                 f"Average range: {self.get_average_range():.2f}m"]
+        if self.statistics:
+            lines += ["", "Simulation Statistics:",
+                      f"  Simulation time: {self.statistics.simulation_time:.2f}s",
+                      f"  Frame rate: {self.statistics.frames_per_second:.1f} FPS"]
+        lines += ["", "Frame Details:", "-" * 30]
+        lines += [f"Frame {i + 1:2d}: {f.get_num_points():5d} points, coverage {f.get_coverage_ratio():.3f}, "
+                  f"density {f.get_scan_density():.3f}" for i, f in enumerate(self.frames)]
+        with open(Path(output_dir) / "simulation_summary.txt", "w", encoding="utf-8") as fh:
+            fh.write("\n".join(lines) + "\n")
+
+    def _export_combined_pointcloud(self, output_dir: Path):
+        """combined_pointcloud.ply: all frames' points, every frame in its own viridis colour i / num_frames
+        (:306-337).  Written as binary PLY with double coordinates and uchar colours, the layout Open3D gives a
+        PointCloud, by this package's writer."""
+        parts, cols = [], []
+        for i, frame in enumerate(self.frames):
+            if len(frame.points) > 0:
+                parts.append(frame.points)
+                cols.append(np.tile(_viridis(i / len(self.frames)), (len(frame.points), 1)))
+        if not parts:
+            return
+        pts = np.vstack(parts).astype(np.float64)
+        rgb = np.clip(np.vstack(cols) * 255.0, 0, 255).astype(np.uint8)
+        rec = np.empty(len(pts), dtype=np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8"),
+                                                 ("red", "u1"), ("green", "u1"), ("blue", "u1")]))
+        rec["x"], rec["y"], rec["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+        rec["red"], rec["green"], rec["blue"] = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+        with open(Path(output_dir) / "combined_pointcloud.ply", "wb") as f:
+            f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty double x\n"
+                    b"property double y\nproperty double z\nproperty uchar red\nproperty uchar green\n"
+                    b"property uchar blue\nend_header\n" % len(pts))
+            rec.tofile(f)
+
+    def _export_combined_pointcloud_with_labels(self, output_dir: Path):
+        """combined_pointcloud_with_label.ply: np.vstack of the non-empty frames with colour, semantic and instance
+        label per point (:339-377)."""
         pts = self.combined_points()
         if len(pts) == 0:
             return
-        if self._annotated is not None:       # reference path: 1-NN into the annotated cloud, per frame (:347-356)
+        has_frame_labels = any(f.semantic_labels is not None for f in self.frames if len(f.points) > 0)
+        if self._annotated is not None or not has_frame_labels:
+            # the reference's path: per frame, colours and labels of the nearest annotated point, or its defaults
             cols, sems, inss = [], [], []
             for f in self.frames:
                 if len(f.points) > 0:
                     c, s_, i_ = self._get_colors_and_labels_from_s3dis(f.points)
                     cols.append(c); sems.append(s_); inss.append(i_)
             colors = (np.vstack(cols) * 255).astype(np.uint8)
-            sem, ins = np.concatenate(sems).astype(np.uint16), np.concatenate(inss).astype(np.uint16)
-        else:                                 # labels written back by the trace kernel; reference default grey
+            sem, ins = np.concatenate(sems), np.concatenate(inss)
+        else:                                 # labels written back by the trace kernel; the reference's default grey
             sem, ins = self.combined_labels()
             colors = np.full((len(pts), 3), int(0.5 * 255), dtype=np.uint8)
-        write_labeled_ply(out / "combined_pointcloud_with_label.ply", pts, colors, sem, ins)
+        self._save_labeled_ply(Path(output_dir) / "combined_pointcloud_with_label.ply", pts, colors, sem, ins)
+
+    def _save_labeled_ply(self, output_path: Path, points: np.ndarray, colors: np.ndarray,
+                          semantic_labels: np.ndarray, instance_labels: np.ndarray):
+        write_labeled_ply(output_path, points, colors, semantic_labels, instance_labels)
+
+    # ---- S3DIS annotation hooks (loaders themselves are out of scope, see the module docstring) ------------
+    def _load_s3dis_txt_pointcloud(self, file_path: str) -> tuple:
+        """``x y z r g b [label]`` text rows -> (points, colours in 0..1); (None, None) on any problem (:482-503)."""
+        try:
+            data = np.loadtxt(file_path)
+            if data.shape[1] < 6:
+                return None, None
+            colors = data[:, 3:6]
+            return data[:, :3], (colors / 255.0 if colors.max() > 1.0 else colors)
+        except Exception:                                          # noqa: BLE001 - the reference swallows everything
+            return None, None
+
+    def _load_s3dis_original_data(self) -> tuple:
+        """The room's raw coloured cloud ``{root}/{area}/{room}/{room}.txt`` (or the *_inst_nostring.txt variant)."""
+        if not self.s3dis_data_root or not self.area or not self.room:
+            return None, None
+        base = f"{self.s3dis_data_root}/{self.area}/{self.room}"
+        for path in (f"{base}/{self.room}.txt", f"{base}/Area_{self.area}_{self.room}_inst_nostring.txt"):
+            if os.path.exists(path):
+                points, colors = self._load_s3dis_txt_pointcloud(path)
+                if points is None or len(points) == 0:
+                    return None, None
+                return points, colors
+        return None, None
+
+    def _annotation_arrays(self):
+        from s3dis_annotation_loader import S3DISAnnotationLoader    # the caller's module, if present
+        loader = S3DISAnnotationLoader(self.s3dis_data_root)
+        rooms = loader.load_room_annotations(self.area, self.room)
+        if not rooms:
+            return None
+        points, sem, ins = loader.create_labeled_pointcloud_with_instances(rooms)
+        return (points, sem, ins) if len(points) else None
+
+    def _load_s3dis_annotations(self) -> tuple:
+        if not self.s3dis_data_root or not self.area or not self.room:
+            return None, None
+        try:
+            got = self._annotation_arrays()
+            return (got[1], got[2]) if got else (None, None)
+        except Exception:                                          # noqa: BLE001
+            return None, None
+
+    def _load_s3dis_annotations_with_colors(self) -> tuple:
+        if not self.s3dis_data_root or not self.area or not self.room:
+            return None, None, None, None
+        try:
+            got = self._annotation_arrays()
+            if not got:
+                return None, None, None, None
+            points, sem, ins = got
+            raw_points, raw_colors = self._load_s3dis_original_data()
+            if raw_points is None or raw_colors is None:
+                colors = np.ones((len(points), 3), dtype=np.float32) * 0.5
+            else:
+                import lidarcast
+                colors = raw_colors[lidarcast.NearestIndex(lidarcast.Context(0), raw_points).query(points)]
+            return points, colors, sem, ins
+        except Exception:                                          # noqa: BLE001
+            return None, None, None, None
+
+    def _decode_colors_to_labels(self, colors: np.ndarray) -> tuple:
+        try:
+            from s3dis_annotation_loader import S3DISColorEncoder
+            return S3DISColorEncoder().decode_colors_to_labels_and_instances(colors)
+        except Exception:                                          # noqa: BLE001
+            return np.zeros(len(colors), dtype=np.uint16), np.zeros(len(colors), dtype=np.uint16)
+
+    # ---- selection, dictionary round trip ----------------------------------------------------------------
+    def filter_frames_by_quality(self, min_coverage: float = 0.0, max_coverage: float = 1.0) -> "S3DISSimScene":
+        kept = S3DISSimScene(self.scene_name, self.simulation_config)
+        kept.frames = [f for f in self.frames if min_coverage <= f.get_coverage_ratio() <= max_coverage]
+        return kept
+
+    def get_best_frames(self, num_frames: int = 10, quality_metric: str = "coverage") -> List[S3DISSimFrame]:
+        keys = {"coverage": S3DISSimFrame.get_coverage_ratio, "points": S3DISSimFrame.get_num_points,
+                "density": S3DISSimFrame.get_scan_density}
+        if quality_metric not in keys:
+            raise ValueError(f"Unsupported quality metric: {quality_metric}")
+        return sorted(self.frames, key=keys[quality_metric], reverse=True)[:num_frames]
+
+    def to_dict(self) -> Dict[str, Any]:
+        return {"scene_name": self.scene_name, "simulation_config": self.simulation_config,
+                "frames": [f.to_dict() for f in self.frames],
+                "statistics": self.statistics.to_dict() if self.statistics else None}
+
+    @classmethod
+    def from_dict(cls, scene_dict: Dict[str, Any]) -> "S3DISSimScene":
+        scene = cls(scene_name=scene_dict["scene_name"], simulation_config=scene_dict.get("simulation_config", {}))
+        for fd in scene_dict["frames"]:
+            scene.append_frame(S3DISSimFrame.from_dict(fd))
+        if scene_dict.get("statistics"):
+            scene.statistics = SimulationStats(**scene_dict["statistics"])
+        return scene
+
+    def __repr__(self) -> str:
+        return (f"S3DISSimScene(name='{self.scene_name}', frames={self.get_total_frames()}, "
+                f"points={self.get_total_points()}, avg_coverage={self.get_average_coverage():.3f})")
+
+
+def _viridis(x: float) -> np.ndarray:
+    """RGB in 0..1 of matplotlib's viridis at x (the reference colours frame i with plt.cm.viridis(i / n));
+    without matplotlib a five-stop linear approximation of the same map."""
+    try:
+        import matplotlib.pyplot as plt
+        return np.asarray(plt.cm.viridis(x)[:3], dtype=np.float64)
+    except Exception:                                              # noqa: BLE001
+        stops = np.array([[0.267, 0.005, 0.329], [0.229, 0.322, 0.546], [0.128, 0.567, 0.551],
+                          [0.369, 0.789, 0.383], [0.993, 0.906, 0.144]])
+        p = min(max(float(x), 0.0), 1.0) * 4
+        i = min(int(p), 3)
+        return stops[i] + (stops[i + 1] - stops[i]) * (p - i)

@@ -1,7 +1,8 @@
 """Pose source of the scan path (import surface of the reference's ``trajectory`` package that the scan needs)."""
 from enum import Enum
 
-from .trajectory_generator import Waypoint, TrajectoryQuality, poses_from_waypoints, line_trajectory
+from .trajectory_generator import (TrajectoryGeneratorBase, Waypoint, TrajectoryQuality, poses_from_waypoints,
+                                   line_trajectory)
 from .auto_trajectory_generator import AutoTrajectoryGenerator, RoomAnalysis, TrajectoryCandidate
 
 
@@ -11,20 +12,21 @@ class PathType(Enum):
     STRAIGHT = "straight"
 
 
-class SmartTrajectoryGenerator:
+class SmartTrajectoryGenerator(TrajectoryGeneratorBase):
     """Also imported but undefined in the reference.  Minimal stand-in with the call shape the
-    simulator uses (s3dis_simulator.py:124-127, :201-206): straight line between two poses at fixed yaw."""
+    simulator uses (s3dis_simulator.py:124-127, :201-206): straight line between two poses at fixed yaw, scored by
+    the base class's measures."""
 
     def __init__(self, room_bounds, robot_height: float = 1.0):
-        self.room_bounds, self.robot_height, self.collision_detector = room_bounds, robot_height, None
+        super().__init__(room_bounds, robot_height)
+        self.collision_detector = None
 
     def generate_trajectory(self, start_point, end_point, path_type=PathType.STRAIGHT, num_waypoints: int = 20):
         if path_type is not PathType.STRAIGHT:
             raise ValueError("only PathType.STRAIGHT is available")
         wps = line_trajectory(start_point, end_point, num_waypoints)
-        length = float(sum(wps[i].distance_to(wps[i + 1]) for i in range(len(wps) - 1)))
-        return wps, TrajectoryQuality(1.0, length, 0, 1.0, 0, 1.0)
+        return wps, self.evaluate_trajectory_quality(wps)
 
 
-__all__ = ["Waypoint", "TrajectoryQuality", "poses_from_waypoints", "line_trajectory", "AutoTrajectoryGenerator",
+__all__ = ["TrajectoryGeneratorBase", "Waypoint", "TrajectoryQuality", "poses_from_waypoints", "line_trajectory", "AutoTrajectoryGenerator",
            "RoomAnalysis", "TrajectoryCandidate", "PathType", "SmartTrajectoryGenerator"]

@@ -1,10 +1,10 @@
-"""Waypoint -> sensor pose (reference: trajectory/trajectory_generator.py:12-61).
-
-Only the pose source of the scan path is provided here; trajectory planning is out of scope
-(SURVEY.md section 8(f), row N2).
+"""Waypoint -> sensor pose, the trajectory quality record and the generator base class
+(reference: trajectory/trajectory_generator.py; results checked against the reference's own class,
+tests/golden/make_trajectory_base_golden.py).  The planner itself is auto_trajectory_generator.py.
 """
+from abc import ABC, abstractmethod
 from dataclasses import dataclass
-from typing import List, Optional
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -55,6 +55,75 @@ class TrajectoryQuality:
         return {"coverage_ratio": self.coverage_ratio, "path_length": self.path_length,
                 "turn_count": self.turn_count, "efficiency": self.efficiency,
                 "collision_count": self.collision_count, "smoothness": self.smoothness}
+
+
+def _yaw_steps(waypoints: List[Waypoint]) -> List[float]:
+    """|yaw[i+1] - yaw[i]| for the interior waypoints i = 1 .. n-2, folded into [0, pi]."""
+    out = []
+    for i in range(1, len(waypoints) - 1):
+        step = abs(waypoints[i + 1].yaw - waypoints[i].yaw)
+        out.append(2 * np.pi - step if step > np.pi else step)
+    return out
+
+
+class TrajectoryGeneratorBase(ABC):
+    """Common measures of a waypoint list (reference: trajectory/trajectory_generator.py:84-241)."""
+
+    def __init__(self, room_bounds: Dict[str, float], robot_height: float = 1.0):
+        self.room_bounds = room_bounds
+        self.robot_height = robot_height
+        self.robot_radius = 0.3
+
+    @abstractmethod
+    def generate_trajectory(self, **kwargs) -> Tuple[List[Waypoint], TrajectoryQuality]:
+        """(waypoints, quality)"""
+
+    def waypoints_to_poses(self, waypoints: List[Waypoint]) -> List[np.ndarray]:
+        return [w.to_pose_matrix() for w in waypoints]
+
+    def calculate_path_length(self, waypoints: List[Waypoint]) -> float:
+        total = 0.0
+        for prev, cur in zip(waypoints, waypoints[1:]):
+            total += cur.distance_to(prev)
+        return total
+
+    def count_turns(self, waypoints: List[Waypoint], angle_threshold: float = 0.1) -> int:
+        """Interior waypoints after which the yaw changes by more than the threshold."""
+        return sum(1 for step in _yaw_steps(waypoints) if step > angle_threshold)
+
+    def calculate_smoothness(self, waypoints: List[Waypoint]) -> float:
+        """1 / (1 + std of the yaw steps); 1.0 for fewer than three waypoints."""
+        steps = _yaw_steps(waypoints)
+        return 1.0 / (1.0 + np.std(steps)) if steps else 1.0
+
+    def is_point_in_room(self, waypoint: Waypoint) -> bool:
+        b = self.room_bounds
+        return (b["x_min"] <= waypoint.x <= b["x_max"] and b["y_min"] <= waypoint.y <= b["y_max"]
+                and b["z_min"] <= waypoint.z <= b["z_max"])
+
+    def clip_to_room_bounds(self, waypoint: Waypoint) -> Waypoint:
+        b = self.room_bounds
+        return Waypoint(x=np.clip(waypoint.x, b["x_min"], b["x_max"]), y=np.clip(waypoint.y, b["y_min"], b["y_max"]),
+                        z=np.clip(waypoint.z, b["z_min"], b["z_max"]), yaw=waypoint.yaw,
+                        timestamp=waypoint.timestamp, velocity=waypoint.velocity,
+                        angular_velocity=waypoint.angular_velocity)
+
+    def _calculate_coverage_ratio(self, waypoints: List[Waypoint]) -> float:
+        """Area of the waypoints' x/y bounding rectangle over the room's floor area, capped at 1."""
+        if not waypoints:
+            return 0.0
+        xy = np.array([[w.x, w.y] for w in waypoints])
+        span = xy.max(axis=0) - xy.min(axis=0)
+        b = self.room_bounds
+        floor = (b["x_max"] - b["x_min"]) * (b["y_max"] - b["y_min"])
+        return min(span[0] * span[1] / floor, 1.0)
+
+    def evaluate_trajectory_quality(self, waypoints: List[Waypoint], collision_count: int = 0) -> TrajectoryQuality:
+        length = self.calculate_path_length(waypoints)
+        coverage = self._calculate_coverage_ratio(waypoints)
+        return TrajectoryQuality(coverage_ratio=coverage, path_length=length, turn_count=self.count_turns(waypoints),
+                                 efficiency=coverage / length if length > 0 else 0,
+                                 collision_count=collision_count, smoothness=self.calculate_smoothness(waypoints))
 
 
 def poses_from_waypoints(waypoints: List[Waypoint]) -> np.ndarray:

@@ -67,7 +67,8 @@ def test_occupancy_kernel_matches_numpy():
 def test_waypoint_helpers_and_missing_reference_names():
     """CPU: the names the reference's simulator imports from ``trajectory`` exist."""
     from trajectory import PathType, SmartTrajectoryGenerator, TrajectoryQuality, Waypoint
-    g = SmartTrajectoryGenerator({"x_min": 0}, robot_height=1.0)
+    g = SmartTrajectoryGenerator({"x_min": 0.0, "x_max": 5.0, "y_min": 0.0, "y_max": 4.0, "z_min": 0.0, "z_max": 3.0},
+                                 robot_height=1.0)
     wps, q = g.generate_trajectory((1, 2, 1), (4, 2, 1), PathType.STRAIGHT, 7)
     assert len(wps) == 7 and isinstance(q, TrajectoryQuality) and abs(q.path_length - 3.0) < 1e-12
     assert isinstance(wps[0], Waypoint) and wps[-1].x == 4 and q.to_dict()["collision_count"] == 0

@@ -31,15 +31,15 @@ def read_triangle_mesh(path) -> TriangleMesh:
             if name == "vertex":
                 dt = np.dtype([(p[-1], "<" + _T[p[0]]) for p in props])
                 if fmt == "ascii":
-                    a = np.loadtxt(f, max_rows=count, ndmin=2)
                     names = [p[-1] for p in props]
+                    a = np.loadtxt(f, max_rows=count, ndmin=2) if count else np.zeros((0, len(names)))
                     verts = np.stack([a[:, names.index(c)] for c in "xyz"], 1)
                 else:
                     a = np.fromfile(f, dtype=dt, count=count)
                     verts = np.stack([a["x"], a["y"], a["z"]], 1).astype(np.float64)
             elif name == "face":
                 if fmt == "ascii":
-                    a = np.loadtxt(f, max_rows=count, ndmin=2).astype(np.int64)
+                    a = np.loadtxt(f, max_rows=count, ndmin=2).astype(np.int64) if count else np.zeros((0, 4), np.int64)
                     faces = a[:, 1:4]
                 else:
                     p = props[0]          # list <count type> <index type> vertex_indices

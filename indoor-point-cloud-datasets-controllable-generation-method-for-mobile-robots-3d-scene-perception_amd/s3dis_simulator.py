@@ -1,24 +1,27 @@
 """Drop-in caller of the engines: the reference's S3DISSimulator scan stage
 (reference: s3dis_simulator.py:36-77 construction, :220-296 run_simulation).
 
-Scope: sensor + engine selection and the scan loop.  Scene loading takes a mesh object (anything with
-``.vertices`` / ``.triangles``) or a PLY path; trajectory planning, visualisation and NKSR
-reconstruction are not part of this package (SURVEY.md section 8(f)).
+Scope: sensor + engine selection, trajectory (planned or straight), the scan loop and the result files, under the
+reference's method names and signatures.  Scene loading takes a mesh object (anything with ``.vertices`` /
+``.triangles``) or a PLY path; visualisation, furniture-aware collision checking, the batch / CLI drivers and NKSR
+reconstruction are not part of this package (DESIGN.md section 9).
 
 ``run_simulation`` keeps the reference's per-frame ScanQuality formulas, including two quirks of the
 reference loop that a drop-in must reproduce to give the same statistics (``bug_compatible=True``):
 the incident angles are overwritten with zeros (:266-269) and the range statistics are norms from the
 WORLD origin, not from the sensor (:283-284).
 """
+import json
 import time
-from typing import Any, Dict, List, Optional
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
 
 from containers import RoomBounds, S3DISScene, S3DISSimFrame, S3DISSimScene, ScanQuality
 from lidar import (DualAxisLidarIntrinsics, Indoor8LineLidarIntrinsics, create_lidar)
 from raycast_engine import RaycastEngineCPU, RaycastEngineGPU
-from trajectory import AutoTrajectoryGenerator, Waypoint, poses_from_waypoints
+from trajectory import AutoTrajectoryGenerator, PathType, SmartTrajectoryGenerator, Waypoint, poses_from_waypoints
 
 
 class S3DISSimulator:
@@ -31,7 +34,9 @@ class S3DISSimulator:
         self.scene: Optional[S3DISScene] = None
         self.lidar_config = None
         self.raycast_engine = None
-        self.auto_trajectory_generator = None
+        self.trajectory_generator: Optional[SmartTrajectoryGenerator] = None
+        self.auto_trajectory_generator: Optional[AutoTrajectoryGenerator] = None
+        self.collision_detector = None          # furniture-aware planning is out of scope
         self._initialize_components()
 
     def _initialize_components(self):
@@ -45,39 +50,87 @@ class S3DISSimulator:
         use_gpu = self.config.get("raycast_engine", {}).get("use_gpu", False)
         self.raycast_engine = RaycastEngineGPU() if use_gpu else RaycastEngineCPU()
 
-    def load_scene(self, scene, scene_name: Optional[str] = None) -> S3DISScene:
-        """scene: mesh object or path to a triangle-mesh PLY."""
-        if isinstance(scene, (str, bytes)) or hasattr(scene, "__fspath__"):
+    def load_scene(self, scene_path, scene_name: Optional[str] = None) -> S3DISScene:
+        """scene_path: path to a triangle-mesh PLY (name defaults to the file stem, reference :78-129), or a mesh
+        object."""
+        if isinstance(scene_path, (str, bytes)) or hasattr(scene_path, "__fspath__"):
             from lidarcast.ply import read_triangle_mesh
-            mesh = read_triangle_mesh(scene)
-            scene_name = scene_name or str(scene).rsplit("/", 1)[-1].rsplit(".", 1)[0]
+            mesh = read_triangle_mesh(scene_path)
+            scene_name = scene_name or Path(str(scene_path)).stem
+            if len(np.asarray(mesh.vertices)) == 0:
+                raise ValueError(f"Failed to load mesh file: {scene_path}")
         else:
-            mesh = scene
-        if len(np.asarray(mesh.vertices)) == 0:
-            raise ValueError("Failed to load mesh: no vertices")
+            mesh = scene_path
+            if len(np.asarray(mesh.vertices)) == 0:
+                raise ValueError("Failed to load mesh: no vertices")
         self.scene = S3DISScene(scene_name or "scene", mesh, RoomBounds.from_vertices(mesh.vertices))
+        self.trajectory_generator = SmartTrajectoryGenerator(
+            self._bounds_dict(), robot_height=self.config.get("trajectory", {}).get("robot_height", 1.0))
         # same planner settings as the reference (s3dis_simulator.py:127): reduced radius for narrow spaces
         self.auto_trajectory_generator = AutoTrajectoryGenerator(robot_radius=0.15, context=self.raycast_engine.ctx)
         return self.scene
 
-    def generate_auto_trajectory(self, num_waypoints: int = 20):
-        """Planned trajectory for the loaded scene (reference s3dis_simulator.py:132-167)."""
-        if self.scene is None:
-            raise ValueError("Scene not loaded. Call load_scene() first.")
+    def _bounds_dict(self) -> Dict[str, float]:
         b = self.scene.room_bounds
-        bounds = {"x_min": b.x_min, "x_max": b.x_max, "y_min": b.y_min, "y_max": b.y_max,
-                  "z_min": b.z_min, "z_max": b.z_max}
-        return self.auto_trajectory_generator.generate_optimal_trajectory(
-            mesh=self.scene.room_mesh, room_bounds=bounds, num_waypoints=num_waypoints)
+        return {"x_min": b.x_min, "x_max": b.x_max, "y_min": b.y_min, "y_max": b.y_max,
+                "z_min": b.z_min, "z_max": b.z_max}
 
-    def run_auto_simulation(self, scene, num_waypoints: int = 20, output_dir=None):
-        """load_scene -> generate_auto_trajectory -> run_simulation (-> save_results), reference :407-444."""
-        self.load_scene(scene)
-        waypoints, analysis = self.generate_auto_trajectory(num_waypoints)
+    def generate_auto_trajectory(self, num_waypoints: int = 20) -> Tuple[List[Waypoint], Dict[str, Any]]:
+        """Planned trajectory for the loaded scene (reference s3dis_simulator.py:132-167)."""
+        if self.auto_trajectory_generator is None or self.scene is None:
+            raise ValueError("Scene not loaded. Call load_scene() first.")
+        return self.auto_trajectory_generator.generate_optimal_trajectory(
+            mesh=self.scene.room_mesh, room_bounds=self._bounds_dict(), num_waypoints=num_waypoints)
+
+    def generate_trajectory(self, start_point: Tuple[float, float, float], end_point: Tuple[float, float, float],
+                            path_type: PathType = PathType.STRAIGHT,
+                            num_waypoints: int = 20) -> Tuple[List[Waypoint], Dict[str, Any]]:
+        """Trajectory between two positions -> (waypoints, quality as a dict) (reference :181-218; the furniture
+        re-planning branch has nothing to act on here)."""
+        if self.trajectory_generator is None:
+            raise ValueError("Scene not loaded. Call load_scene() first.")
+        waypoints, quality = self.trajectory_generator.generate_trajectory(
+            start_point=start_point, end_point=end_point, path_type=path_type, num_waypoints=num_waypoints)
+        return waypoints, quality.to_dict()
+
+    def add_furniture(self, furniture_mesh, name: str, category: str = "unknown"):
+        """The reference forwards this to its CollisionDetector, which does not import; furniture
+        that is part of the room mesh occludes rays without it."""
+        raise NotImplementedError("furniture-aware collision checking is out of scope (DESIGN.md section 9); "
+                                  "put the furniture into the room mesh")
+
+    def save_results(self, sim_scene: S3DISSimScene, output_dir, waypoints: Optional[List[Waypoint]] = None,
+                     save_visualizations: bool = True):
+        """Result files of the scene (statistics, summary, both combined clouds; reference :298-371).  The
+        visualisations the reference adds are out of scope; the flag is accepted and ignored."""
+        sim_scene.save_results(Path(output_dir))
+
+    def run_complete_simulation(self, scene_path, start_point: Tuple[float, float, float],
+                                end_point: Tuple[float, float, float], path_type: PathType = PathType.STRAIGHT,
+                                num_waypoints: int = 20, output_dir=None,
+                                scene_name: Optional[str] = None) -> S3DISSimScene:
+        """load_scene -> generate_trajectory -> run_simulation -> save_results (reference :373-413)."""
+        self.load_scene(scene_path, scene_name)
+        waypoints, _ = self.generate_trajectory(start_point, end_point, path_type, num_waypoints)
         sim_scene = self.run_simulation(waypoints)
-        if output_dir is not None:
-            sim_scene.save_results(output_dir)
-        return sim_scene, waypoints, analysis
+        self.save_results(sim_scene, Path("s3dis_simulation_results") if output_dir is None else Path(output_dir),
+                          waypoints)
+        return sim_scene
+
+    def run_auto_simulation(self, scene_path, num_waypoints: int = 20, output_dir=None,
+                            scene_name: Optional[str] = None) -> S3DISSimScene:
+        """load_scene -> generate_auto_trajectory -> run_simulation -> save_results + trajectory_analysis.json
+        (reference :415-455).  The planned waypoints and the planner's report stay available as
+        ``last_waypoints`` / ``last_analysis``."""
+        self.load_scene(scene_path, scene_name)
+        waypoints, analysis = self.generate_auto_trajectory(num_waypoints)
+        self.last_waypoints, self.last_analysis = waypoints, analysis
+        sim_scene = self.run_simulation(waypoints)
+        out = Path("s3dis_auto_simulation_results") if output_dir is None else Path(output_dir)
+        self.save_results(sim_scene, out, waypoints)
+        with open(out / "trajectory_analysis.json", "w", encoding="utf-8") as f:
+            json.dump(analysis, f, indent=2, ensure_ascii=False)
+        return sim_scene
 
     # ---- the scan stage ---------------------------------------------------------------------------
     def _quality(self, points, incident_angles, total_points_per_scan, room_volume) -> ScanQuality:
@@ -130,3 +183,20 @@ class S3DISSimulator:
                                                  instance_labels=ins))
         sim_scene.compute_statistics(time.time() - start)
         return sim_scene
+
+
+def load_config(config_path: str) -> Dict[str, Any]:
+    """YAML configuration file -> dict (reference :458-465)."""
+    import yaml
+    with open(config_path, "r", encoding="utf-8") as f:
+        return yaml.safe_load(f)
+
+
+def load_default_config() -> Dict[str, Any]:
+    """configs/default_config.yaml next to this module (the reference looks for the same file and does not ship
+    it either: FileNotFoundError there and here)."""
+    return load_config(str(Path(__file__).parent / "configs" / "default_config.yaml"))
+
+
+def create_simulator_from_config(config_path: Optional[str] = None) -> S3DISSimulator:
+    return S3DISSimulator(load_default_config() if config_path is None else load_config(config_path))

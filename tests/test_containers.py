@@ -2,6 +2,7 @@
 import struct
 
 import numpy as np
+import pytest
 
 from containers import (S3DISSimFrame, S3DISSimScene, ScanQuality, read_labeled_ply, write_labeled_ply)
 
@@ -59,3 +60,44 @@ def test_mesh_ply_roundtrip(tmp_path):
     write_triangle_mesh(tmp_path / "m.ply", m)
     r = read_triangle_mesh(tmp_path / "m.ply")
     assert np.array_equal(r.triangles, m.triangles) and np.allclose(r.vertices, m.vertices)
+
+
+def test_scene_record_surface(tmp_path):
+    """RoomBounds / SemanticInfo / S3DISScene: the reference's names and values (containers/s3dis_scene.py:13-218)."""
+    from containers import RoomBounds, S3DISScene, SemanticInfo
+    from lidarcast import synth
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=1, seed=1, cell=0.5)
+    b = RoomBounds.from_mesh(mesh)
+    v = np.asarray(mesh.vertices)
+    assert b.to_dict() == {"x_min": v[:, 0].min(), "x_max": v[:, 0].max(), "y_min": v[:, 1].min(),
+                           "y_max": v[:, 1].max(), "z_min": v[:, 2].min(), "z_max": v[:, 2].max()}
+    assert RoomBounds.from_dict(b.to_dict()) == b
+    size = b.get_size()
+    assert np.array_equal(size, v.max(axis=0) - v.min(axis=0)) and b.get_volume() == size[0] * size[1] * size[2]
+    assert np.array_equal(b.get_center(), (v.max(axis=0) + v.min(axis=0)) / 2)
+    assert b.is_point_inside(b.get_center()) and not b.is_point_inside(b.get_center() + size)
+    info = SemanticInfo("office")
+    info.add_furniture("desk", np.array([1.0, 2.0, 0.4]), np.array([1.2, 0.6, 0.8]), "table")
+    assert info.get_furniture_count() == 1
+    assert info.to_dict() == {"room_type": "office", "semantic_labels": {},
+                              "furniture_info": {"desk": {"position": [1.0, 2.0, 0.4], "size": [1.2, 0.6, 0.8],
+                                                          "category": "table"}}}
+    sc = S3DISScene("room_a", mesh, semantic_info=info)
+    assert sc.room_bounds == b and sc.num_vertices == len(v) and sc.num_triangles == len(mesh.triangles)
+    assert sc.mesh_volume == b.get_volume() and sc.is_point_inside(sc.get_bounds_center())
+    assert np.array_equal(sc.get_bounds_size(), size)
+    assert sc.get_mesh_statistics() == {"num_vertices": len(v), "num_triangles": len(mesh.triangles),
+                                        "volume": b.get_volume(), "bounds": b.to_dict()}
+    assert sorted(sc.to_dict()) == ["mesh_statistics", "room_bounds", "scene_name", "semantic_info"]
+    assert repr(sc) == f"S3DISScene(name='room_a', vertices={len(v)}, triangles={len(mesh.triangles)}, bounds={size})"
+    sc.save_mesh(tmp_path / "sub" / "room_a.ply")
+    sc2 = S3DISScene.from_mesh_file("again", tmp_path / "sub" / "room_a.ply")
+    assert sc2.num_triangles == sc.num_triangles and sc2.semantic_info.get_furniture_count() == 0
+    assert np.allclose(sc2.room_bounds.get_size(), size, atol=1e-6)       # PLY stores float32 coordinates
+    assert not sc2.load_mesh(tmp_path / "missing.ply")
+    assert sc2.load_mesh(tmp_path / "sub" / "room_a.ply") and sc2.num_vertices == len(v)
+    (tmp_path / "empty.ply").write_text("ply\nformat ascii 1.0\nelement vertex 0\nproperty float x\nproperty float y\n"
+                                        "property float z\nelement face 0\nproperty list uchar int vertex_indices\n"
+                                        "end_header\n")
+    with pytest.raises(ValueError):
+        S3DISScene.from_mesh_file("none", tmp_path / "empty.ply")

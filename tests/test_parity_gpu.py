@@ -427,6 +427,48 @@ def test_device_path_fused_tile_counts_and_packed_rows(ctx):
         assert np.array_equal(tc, pad.reshape(-1, 64).sum(1))
 
 
+def test_simulator_workflows_write_the_reference_file_set(tmp_path):
+    """run_complete_simulation / run_auto_simulation under the reference's signatures: scene from a PLY path, straight
+    or planned trajectory, scan, result files (reference s3dis_simulator.py:373-455)."""
+    import json
+    import s3dis_simulator
+    from containers import read_labeled_ply
+    from lidarcast import ply, synth
+    from trajectory import PathType
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=3, seed=2, cell=0.08)
+    path = tmp_path / "office_9.ply"
+    ply.write_triangle_mesh(path, mesh)
+    sim = s3dis_simulator.S3DISSimulator({"raycast_engine": {"use_gpu": True}, "trajectory": {"robot_height": 1.1}})
+    with pytest.raises(ValueError):
+        sim.generate_trajectory((1, 1, 1), (2, 1, 1))                 # no scene yet
+    with pytest.raises(ValueError):
+        sim.generate_auto_trajectory(5)
+    sc = sim.run_complete_simulation(str(path), (1.0, 1.5, 1.0), (3.0, 1.5, 1.0), PathType.STRAIGHT, 5,
+                                     output_dir=tmp_path / "a")
+    assert sim.scene.scene_name == "office_9" and sim.trajectory_generator.robot_height == 1.1
+    assert sc.get_total_frames() == 5 and sc.get_total_points() > 1000
+    assert sorted(p.name for p in (tmp_path / "a").iterdir()) == [
+        "combined_pointcloud.ply", "combined_pointcloud_with_label.ply", "simulation_statistics.txt",
+        "simulation_summary.txt"]
+    assert len(read_labeled_ply(tmp_path / "a" / "combined_pointcloud_with_label.ply")) == sc.get_total_points()
+    wps, q = sim.generate_trajectory((1.0, 1.5, 1.0), (3.0, 1.5, 1.0), num_waypoints=9)
+    assert len(wps) == 9 and isinstance(q, dict) and abs(q["path_length"] - 2.0) < 1e-12
+    np.random.seed(4)
+    sc2 = sim.run_auto_simulation(str(path), num_waypoints=6, output_dir=tmp_path / "b", scene_name="auto_room")
+    assert sim.scene.scene_name == "auto_room" and sc2.get_total_frames() == len(sim.last_waypoints) > 0
+    with open(tmp_path / "b" / "trajectory_analysis.json") as f:
+        assert json.load(f) == json.loads(json.dumps(sim.last_analysis))
+    assert (tmp_path / "b" / "combined_pointcloud_with_label.ply").exists()
+    with pytest.raises(NotImplementedError):
+        sim.add_furniture(mesh, "desk")
+    with pytest.raises(FileNotFoundError):
+        s3dis_simulator.load_default_config()
+    cfg = tmp_path / "c.yaml"
+    cfg.write_text("raycast_engine:\n  use_gpu: true\ntrajectory:\n  robot_height: 0.8\n")
+    sim3 = s3dis_simulator.create_simulator_from_config(str(cfg))
+    assert sim3.config["trajectory"]["robot_height"] == 0.8
+
+
 def test_cloud_rebuilt_from_triangle_ids(ctx):
     """What the multi-GPU all-gather moves is 4 bytes per ray, the hit triangle's row: the rows rebuilt from ids
     alone (t recomputed by the same ray/triangle test) equal the local compaction bit for bit -- over one

@@ -43,7 +43,9 @@ gpu_grid_s = time.perf_counter() - t0
 sim2 = s3dis_simulator.S3DISSimulator({"raycast_engine": {"use_gpu": True}}, use_dense_lidar=True)
 np.random.seed(0)
 t0 = time.perf_counter()
-scene, wps2, _ = sim2.run_auto_simulation(mesh, num_waypoints=64)
+sim2.load_scene(mesh)                                   # run_auto_simulation without its result files
+wps2, _ = sim2.generate_auto_trajectory(64)
+scene = sim2.run_simulation(wps2)
 auto_s = time.perf_counter() - t0
 print(json.dumps({
     "vertices": int(len(v)), "grid_positions": n_grid, "candidates": info["total_candidates"],

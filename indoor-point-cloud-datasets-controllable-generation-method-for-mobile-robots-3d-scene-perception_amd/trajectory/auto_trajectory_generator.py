@@ -89,6 +89,34 @@ class AutoTrajectoryGenerator:
             return np.zeros(len(pts), dtype=bool)
         return self._occupancy(mesh).occupied(pts, self.robot_radius)
 
+    # the reference's per-position forms of the two tests, and the helpers built on them (:204-243, :404-411)
+    def _is_point_in_room_bounds(self, point: np.ndarray, room_bounds: Dict[str, float]) -> bool:
+        return bool(self._in_room_bounds(np.asarray(point, dtype=np.float64)[None, :], room_bounds)[0])
+
+    def _is_point_inside_mesh(self, point: np.ndarray, mesh) -> bool:
+        return bool(self._blocked(np.asarray(point, dtype=np.float64)[None, :], mesh)[0])
+
+    def _has_sufficient_free_space(self, point: np.ndarray, mesh) -> bool:
+        return not self._is_point_inside_mesh(point, mesh)
+
+    @staticmethod
+    def _find_nearest_free_space_point(point: np.ndarray, free_space_points: List[np.ndarray]) -> Optional[int]:
+        """Index of the closest free-space sample (first one on ties), None without samples."""
+        if not free_space_points:
+            return None
+        return np.argmin([np.linalg.norm(np.array(p) - point) for p in free_space_points])
+
+    # furniture-aware planning: the reference forwards these to its CollisionDetector, which does not import
+    # (SURVEY.md F8); out of scope (DESIGN.md section 9) -- furniture inside the room mesh is seen by the cube test
+    def add_furniture(self, furniture):
+        raise NotImplementedError("furniture-aware collision checking is out of scope; merge furniture into the mesh")
+
+    def add_furniture_from_mesh(self, mesh, name: str, category: str = "unknown"):
+        raise NotImplementedError("furniture-aware collision checking is out of scope; merge furniture into the mesh")
+
+    def clear_furniture(self):
+        """Nothing is ever registered, so there is nothing to clear."""
+
     # ---- room analysis --------------------------------------------------------------------------------
     def _sample_free_space(self, mesh, b, resolution):
         xs = np.arange(b["x_min"], b["x_max"], resolution)
@@ -108,8 +136,15 @@ class AutoTrajectoryGenerator:
             self.min_trajectory_length = max(dims[0], dims[1]) * 0.2
         free, blocked = self._sample_free_space(mesh, b, max(0.2, min(dims) / 20))
         if len(free) < 10:                                           # finer second attempt (reference :162-201)
-            free, blocked = self._sample_free_space(mesh, b, max(0.15, min(dims) / 30))
+            return self._analyze_room_layout_detailed(mesh, b, center, dims)
         return RoomAnalysis(bounds=b, center=center, dimensions=dims, free_space_points=free,
+                            obstacle_points=blocked, connectivity_graph=self._build_connectivity_graph(free),
+                            mesh=mesh)
+
+    def _analyze_room_layout_detailed(self, mesh, room_bounds, center: np.ndarray, dimensions: np.ndarray) -> RoomAnalysis:
+        """The same analysis on a finer grid, max(0.15, min(dimensions) / 30) (reference :162-201)."""
+        free, blocked = self._sample_free_space(mesh, room_bounds, max(0.15, min(dimensions) / 30))
+        return RoomAnalysis(bounds=room_bounds, center=center, dimensions=dimensions, free_space_points=free,
                             obstacle_points=blocked, connectivity_graph=self._build_connectivity_graph(free),
                             mesh=mesh)
 

@@ -100,4 +100,6 @@ def evaluate_clouds(X, Y, max_points=10000, volume_threshold=0.3):
     xn, yn = a["normalized_points"], b["normalized_points"]
     return {"mmd": compute_mmd_sampled(xn, yn, max_points), "cd": compute_chamfer_distance(xn, yn),
             "hd": compute_hausdorff_distance(xn, yn), "density_ratio": a["density"] / b["density"],
+            "s3dis_points": len(X), "lidar_net_points": len(Y), "s3dis_density": a["density"],
+            "lidar_net_density": b["density"], "s3dis_volume": a["volume"], "lidar_net_volume": b["volume"],
             "volume_diff": vdiff}

@@ -70,3 +70,40 @@ def write_triangle_mesh(path, mesh):
         rec = np.empty(len(t), dtype=np.dtype([("n", "u1"), ("i", "<i4", (3,))]))
         rec["n"], rec["i"] = 3, t
         rec.tofile(f)
+
+
+def read_point_cloud(path) -> np.ndarray:
+    """(N,3) float64 vertex coordinates of any PLY this module can parse (point clouds written by
+    containers.S3DISSimScene, Open3D-style double/float clouds, meshes).  Stands in for
+    o3d.io.read_point_cloud at reference evaluate_single_scene.py:15-23."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError("not a PLY file")
+        fmt, count, props, current, seen_vertex = None, 0, [], None, False
+        while True:
+            tok = f.readline().decode("ascii", "replace").split()
+            if not tok:
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                current = tok[1]
+                if current == "vertex":
+                    count, seen_vertex = int(tok[2]), True
+                elif not seen_vertex:
+                    raise ValueError("the vertex element must come first")
+            elif tok[0] == "property" and current == "vertex":
+                props.append(tok[1:])
+            elif tok[0] == "end_header":
+                break
+        if not seen_vertex:
+            raise ValueError("PLY has no vertex element")
+        names = [p[-1] for p in props]
+        if fmt == "ascii":
+            a = np.loadtxt(f, max_rows=count, ndmin=2) if count else np.zeros((0, len(names)))
+            return np.stack([a[:, names.index(c)] for c in "xyz"], 1).astype(np.float64)
+        if fmt != "binary_little_endian":
+            raise ValueError(f"unsupported PLY format {fmt}")
+        dt = np.dtype([(p[-1], "<" + _T[p[0]]) for p in props])
+        a = np.fromfile(f, dtype=dt, count=count)
+        return np.stack([a["x"], a["y"], a["z"]], 1).astype(np.float64)

@@ -112,3 +112,37 @@ def test_metrics_reproduce_reference_values():
     assert abs(metrics.rbf_kernel_sum(a, b, 0.7) - np.exp(-0.7 * d2).sum()) < 1e-8 * d2.size
     with pytest.raises(ValueError):
         metrics.min_distances(a, np.zeros((0, 3), np.float32))
+
+
+@pytest.mark.gpu
+def test_evaluate_single_scene_module(tmp_path):
+    """The reference's module name and call shape (evaluate_single_scene.py:15-23, :165-209): two PLY files in, the
+    metric dictionary out; the same values as the in-memory functions; None for unreadable files or incompatible
+    volumes."""
+    import evaluate_single_scene as ess
+    from containers import write_labeled_ply
+    from lidarcast import metrics
+    g = np.load(os.path.join(REPO, "tests", "golden", "metrics_golden.npz"))
+    X, Y = g["X"][:3000].astype(np.float32), g["Y"][:2500].astype(np.float32)
+    z8, z16 = np.zeros((len(X), 3), np.uint8), np.zeros(len(X), np.uint16)
+    write_labeled_ply(tmp_path / "x.ply", X, z8, z16, z16)
+    with open(tmp_path / "y.ply", "wb") as f:                       # Open3D-style cloud: double coordinates + colours
+        rec = np.zeros(len(Y), dtype=[("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("red", "u1"), ("green", "u1"),
+                                      ("blue", "u1")])
+        rec["x"], rec["y"], rec["z"] = Y[:, 0], Y[:, 1], Y[:, 2]
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty double x\nproperty double y\n"
+                b"property double z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % len(Y))
+        rec.tofile(f)
+    px, py = ess.load_point_cloud(str(tmp_path / "x.ply")), ess.load_point_cloud(str(tmp_path / "y.ply"))
+    assert px.dtype == np.float64 and np.array_equal(px, X.astype(np.float64)) and np.array_equal(py, Y.astype(np.float64))
+    np.random.seed(5)
+    got = ess.evaluate_single_scene(str(tmp_path / "x.ply"), str(tmp_path / "y.ply"), max_points=2000, volume_threshold=0.9)
+    np.random.seed(5)
+    want = metrics.evaluate_clouds(px, py, max_points=2000, volume_threshold=0.9)
+    assert got == want and sorted(got) == sorted(
+        ["mmd", "cd", "hd", "density_ratio", "s3dis_points", "lidar_net_points", "s3dis_density", "lidar_net_density",
+         "s3dis_volume", "lidar_net_volume", "volume_diff"])
+    assert got["s3dis_points"] == len(X) and got["lidar_net_points"] == len(Y)
+    assert ess.evaluate_single_scene(str(tmp_path / "x.ply"), str(tmp_path / "nope.ply")) is None
+    write_labeled_ply(tmp_path / "big.ply", X * 3.0, z8, z16, z16)
+    assert ess.evaluate_single_scene(str(tmp_path / "x.ply"), str(tmp_path / "big.ply"), volume_threshold=0.3) is None

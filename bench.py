@@ -152,7 +152,13 @@ def main():
     if world > 1 or args.dist_selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        # "nccl" IS RCCL on ROCm.  LRC_DIST_BACKEND=gloo is a rehearsal aid: several ranks sharing ONE GPU (which RCCL
+        # refuses) run the same sharding / gather / rebuild code with the collective staged through the host.
+        backend = os.environ.get("LRC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- scene (replicated) and inputs, resident in HBM before the timed region ----
     mesh = synth.make_scene(args.scene)

@@ -631,6 +631,35 @@ def test_bench_contract():
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(r["cpu_baseline"]) and r["cpu_baseline"]["kind"] == "port"
 
 
+def test_two_rank_launch_of_the_bench_path():
+    """The N > 1 path launched the way the driver launches it (torch.distributed.run, one process per rank), two
+    ranks sharing this one GPU with the collective staged through gloo (RCCL refuses two ranks on one device): pose
+    sharding by rank, the gather of triangle ids, and on EVERY rank a rebuilt scene cloud equal to the local
+    compaction of all ranks' poses, bit for bit.  (With world size 1 the same code runs through RCCL: the
+    --dist-selftest runs in DESIGN.md section 6.)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, LRC_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-selftest"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count("dist selftest ok") == 2 and "world 2" in r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1                                      # rank 0 alone prints
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and "cpu_baseline" not in res
+    assert res["config"]["rays_per_step_per_gpu"] == 64 * 65536 and 0.99 < res["config"]["hit_fraction"] <= 1.0
+
+
 def test_cast_segments_ragged_poses(engine, a1):
     """BLK2GO poses (ragged ray sets on one seeded stream) in one launch == pose-by-pose calls == oracle."""
     from lidar import DualAxisLidarIntrinsics, create_lidar

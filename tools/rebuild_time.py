@@ -61,6 +61,24 @@ for wc in (True, False):
           f"{(W*n*4 + k*16)/ms/1e6:.0f} GB/s (ids in + rows out)", flush=True)
 k = int(counts.sum().item())
 print("checksum", int(cloud[:k].view(torch.int32).to(torch.int64).sum().item()), k, flush=True)
+# the 8-byte (t, label) payload for comparison: same scans, pairs written contiguously, rebuild without plane gathers
+pairs = torch.empty((W * n, 2), dtype=torch.int32, device=dev)
+hits2 = lidarcast.DeviceHits(n, dev, want=("t", "t_label"))
+for v in range(W):
+    hits2.struct.t_label = pairs[v * n:].data_ptr()
+    scene.scan_poses_dev(d_poses[v * P:(v + 1) * P], d_dirs, hits2, sensor.max_range, st)
+for _ in range(3):
+    ctx.cloud_from_ranges_dev(d_poses, d_dirs, pairs, cloud, counts, st)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    ctx.cloud_from_ranges_dev(d_poses, d_dirs, pairs, cloud, counts, st)
+e1.record()
+torch.cuda.synchronize()
+k2 = int(counts.sum().item())
+print(f"W={W} (t,label) pairs, counting pass included: {e0.elapsed_time(e1)/20*1e3:.1f} us per rebuild; checksum",
+      int(cloud[:k2].view(torch.int32).to(torch.int64).sum().item()), k2, flush=True)
 # reference point: plain fill of the same output
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -9,7 +9,7 @@ C5: the C3 sensor over synth_A1..A6, 64 poses each; aggregate rays/s + per-scene
     evaluate_single_scene.py:81-96 evaluated on the full clouds; 0.0 because the clouds are bit-identical).
 Prints one JSON object (profiles/r01_c4_c5.json is a saved run).
 
-Several GPUs: launch with ``python -m torch.distributed.run --nproc-per-node N tools/run_configs.py``.  C4 then shards
+Several GPUs: launch with ``python -m torch.distributed.run --nproc-per-node N tests/configs/run_configs.py``.  C4 then shards
 the poses in contiguous blocks (every rank draws the whole seeded ray stream and keeps its block, so the rays do not
 depend on N), casts its block, compacts it to 16-byte rows and joins ONE all-gather (lidarcast.distributed.CloudGather);
 the SHA-256 of the assembled cloud is printed and is the same for every N.  C5 deals the scenes round-robin and
@@ -19,7 +19,7 @@ import os
 import sys
 import time
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 import bench  # noqa: E402
 import numpy as np  # noqa: E402

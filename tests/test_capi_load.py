@@ -50,3 +50,31 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(root, fn), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
                 assert "liblrc_oracle" not in src and "orc_cast" not in src, fn
+
+
+def test_oracle_is_only_used_where_it_may_be():
+    """oracle/ is test infrastructure: besides tests/, only bench.py's cpu_baseline leg and __graft_entry__'s
+    build()/smoke() may touch it; tools/ and the package never do."""
+    import ast
+    from conftest import REPO
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for root, _, files in os.walk(os.path.join(REPO, "tools")):
+        for fn in files:
+            assert not pat.search(open(os.path.join(root, fn), errors="replace").read()), f"tools/{fn} imports oracle"
+
+    def importers(path):
+        """names of the top-level functions of a module that import oracle (None = module level)"""
+        tree = ast.parse(open(path).read())
+        found = set()
+        for top in tree.body:
+            for node in ast.walk(top):
+                mods = []
+                if isinstance(node, ast.Import):
+                    mods = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    mods = [node.module or ""]
+                if any(m == "oracle" or m.startswith("oracle.") for m in mods):
+                    found.add(top.name if isinstance(top, (ast.FunctionDef, ast.ClassDef)) else None)
+        return found
+    assert importers(os.path.join(REPO, "bench.py")) <= {"cpu_baseline"}
+    assert importers(os.path.join(REPO, "__graft_entry__.py")) <= {"build", "smoke"}

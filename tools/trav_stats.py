@@ -32,3 +32,10 @@ print(f"uniform (scalar) node steps per ray: {uni.mean():.2f} = {uni.mean() / no
 print(f"dead node steps (no child hit) per ray: {dead.mean():.2f} = {dead.mean() / nodes.mean():.0%} of node steps")
 work = nodes * 45 + tris * 40
 print(f"work balance inside a wave (mean/max of 45*nodes+40*tris): {work.mean() / work.max(1).mean():.2f}")
+# What would K rays per lane with private refill buy (a lane starts its next ray as soon as it finishes one; the wave
+# ends when its slowest lane is through)?  Upper bound from the per-ray work: mean/max over lanes of the K-ray sums.
+flat_nodes, flat_tris = nodes.reshape(-1), tris.reshape(-1)
+w = flat_nodes * 45 + flat_tris * 40
+for K in (1, 2, 4, 8):
+    for how, arr in (("next tiles of the scanline", w[:len(w) // (64 * K) * 64 * K].reshape(-1, K, 64).sum(1)),):
+        print(f"K={K} rays per lane ({how}): work balance mean/max = {arr.mean() / arr.max(1).mean():.2f}")

@@ -212,9 +212,9 @@ __device__ __forceinline__ void rebuild_tiles(const RebuildParams& q, uint32_t t
         const double* M = q.poses16 + (size_t)seg[k] * 16;
         // gen_ray, with the direction already in registers (same FMA chain, lrc_device.h)
         V3 o, d, h, pt;
-        d.x = (float)__builtin_fma(dc[k], M[2], __builtin_fma(db[k], M[1], da[k] * M[0]));
-        d.y = (float)__builtin_fma(dc[k], M[6], __builtin_fma(db[k], M[5], da[k] * M[4]));
-        d.z = (float)__builtin_fma(dc[k], M[10], __builtin_fma(db[k], M[9], da[k] * M[8]));
+        d.x = (float)dgemm_row(da[k], db[k], dc[k], M[0], M[1], M[2]);
+        d.y = (float)dgemm_row(da[k], db[k], dc[k], M[4], M[5], M[6]);
+        d.z = (float)dgemm_row(da[k], db[k], dc[k], M[8], M[9], M[10]);
         o.x = (float)M[3]; o.y = (float)M[7]; o.z = (float)M[11];
         // the sender's scan established that this ray hits this triangle; t is the expression tri_hit evaluates
         // (T/|den| with T = Ng.(v0-O), den = Ng.D, sign-corrected), so v0 and Ng are all that is needed

@@ -99,10 +99,17 @@ LRC_DI bool tri_hit(V3 o, V3 d, const RaySlab& s, V3 v0, V3 v1, V3 v2, V3 ng, fl
     return true;
 }
 
+// One output of np.dot(directions, R.T): the BLAS kernel accumulates over k from a +0.0 accumulator with fused
+// multiply-adds.  The accumulator matters for signed zeros only: (-0.0)*r or 0.0*(-r) alone would be -0.0, dgemm gives
+// +0.0 -- and the sign of a zero direction component decides which side of a box plane an in-plane ray is on.
+LRC_DI double dgemm_row(double a, double b, double c, double r0, double r1, double r2) {
+    return __builtin_fma(c, r2, __builtin_fma(b, r1, __builtin_fma(a, r0, 0.0)));
+}
+
 // Ray (pose, i) of a pose-batched scan: origin = float32(pose[:3,3]); direction = float32(dirs3[i] @ R^T).
 // The reference forms the product with np.dot(directions, pose[:3,:3].T) in float64 (lidar/indoor_lidar.py:127-131),
 // i.e. BLAS dgemm, whose kernels accumulate over k with fused multiply-adds: out_j = fma(c, R[j][2],
-// fma(b, R[j][1], a*R[j][0])).  Reproduced here term for term, so the float64 product -- and hence the float32
+// fma(b, R[j][1], fma(a, R[j][0], +0))).  Reproduced here term for term (dgemm_row), so the float64 product -- and hence the float32
 // direction -- is bit-identical for rotated poses too (checked against vectors captured from the reference at
 // yaw 0.7, tests/golden/).  c = pose[:3,3] in float64.
 LRC_DI void gen_ray(const double* poses16, const double* dirs3, uint64_t pose, uint64_t i, V3& o, V3& d,
@@ -110,9 +117,9 @@ LRC_DI void gen_ray(const double* poses16, const double* dirs3, uint64_t pose, u
     const double* M = poses16 + pose * 16;
     const double* dv = dirs3 + i * 3;
     const double a = dv[0], b = dv[1], c = dv[2];
-    d.x = (float)__builtin_fma(c, M[2], __builtin_fma(b, M[1], a * M[0]));
-    d.y = (float)__builtin_fma(c, M[6], __builtin_fma(b, M[5], a * M[4]));
-    d.z = (float)__builtin_fma(c, M[10], __builtin_fma(b, M[9], a * M[8]));
+    d.x = (float)dgemm_row(a, b, c, M[0], M[1], M[2]);
+    d.y = (float)dgemm_row(a, b, c, M[4], M[5], M[6]);
+    d.z = (float)dgemm_row(a, b, c, M[8], M[9], M[10]);
     cx = M[3]; cy = M[7]; cz = M[11];
     o.x = (float)cx; o.y = (float)cy; o.z = (float)cz;
 }

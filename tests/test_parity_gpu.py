@@ -469,6 +469,37 @@ def test_simulator_workflows_write_the_reference_file_set(tmp_path):
     assert sim3.config["trajectory"]["robot_height"] == 0.8
 
 
+def test_in_kernel_rays_keep_the_sign_of_zero_components(ctx):
+    """np.dot(directions, R.T) runs through dgemm, which accumulates from +0.0: a zero component of a rotated
+    direction is +0.0 even when its only non-zero product is -0.0.  The in-kernel generator must give the same sign,
+    because for a ray that lies exactly in a box plane the sign of the zero decides hit or miss.  Direction tables with
+    exact (signed) zeros, origins on the planes of a unit cube and of a snapped triangle soup: pose-batched scan ==
+    cast of the host-generated rays, bit for bit."""
+    import lidarcast
+    from lidarcast import synth
+    cube = synth.unit_cube()
+    rng = np.random.default_rng(3)
+    soup_v = rng.choice([-1.0, -0.5, 0.0, 0.25, 0.5, 1.0, 2.0], size=(90, 3))
+    soup_f = np.arange(90).reshape(-1, 3)
+    comps = [0.0, -0.0, 1.0, -1.0, 0.5]
+    dirs = np.array([[a, b, c] for a in comps for b in comps for c in comps if (a, b, c) != (0.0, 0.0, 0.0)
+                     and any(x != 0 for x in (a, b, c))], dtype=np.float64)
+    poses = np.stack([pose(x, y, z, yaw=yaw) for (x, y, z) in ((0.0, 0.0, 0.0), (0.5, 0.5, 0.5), (-1.0, 2.0, 1.0),
+                                                                (1.0, 0.25, 0.0))
+                      for yaw in (0.0, 0.5, np.pi / 2, np.pi, -2.0)])
+    for v, f in ((np.asarray(cube.vertices), np.asarray(cube.triangles)), (soup_v, soup_f)):
+        scene = lidarcast.Scene(ctx, v, f)
+        got = {k: a.reshape(len(poses), len(dirs)) for k, a in
+               scene.scan_poses(poses, dirs, 100.0, want=("t", "prim")).items()}
+        for p, m in enumerate(poses):
+            d = np.dot(dirs, m[:3, :3].T).astype(np.float32)
+            o = np.repeat(m[:3, 3][None, :], len(dirs), 0).astype(np.float32)
+            ref = scene.cast(np.concatenate([o, d], 1), center=m[:3, 3], max_range=100.0, want=("t", "prim"))
+            assert_bit_equal(got["t"][p], ref["t"], f"pose {p}")
+            assert_bit_equal(got["prim"][p], ref["prim"], f"pose {p}")
+        scene.close()
+
+
 def test_cloud_rebuilt_from_triangle_ids(ctx):
     """What the multi-GPU all-gather moves is 4 bytes per ray, the hit triangle's row: the rows rebuilt from ids
     alone (t recomputed by the same ray/triangle test) equal the local compaction bit for bit -- over one

@@ -71,3 +71,61 @@ def test_hip_equals_definition(scene):
     assert_bit_equal(out["t"], tb)
     assert_bit_equal(out["prim"], pb)
     assert_bit_equal(out["normal3"], om.normals(pb))
+
+
+@pytest.mark.gpu
+@settings(max_examples=int(os.environ.get("LRC_HYPOTHESIS_EXAMPLES", 25)), deadline=None, derandomize="LRC_HYPOTHESIS_EXAMPLES" not in os.environ,
+          suppress_health_check=list(HealthCheck))
+@given(scenes(), st.integers(1, 4), st.booleans())
+def test_cloud_rebuilt_from_ids_on_adversarial_scenes(scene, num_poses, aligned):
+    """Pose-batched scan of the same adversarial scenes (the rays' directions become the sensor's direction table,
+    poses are yawed and snapped): the scan equals the definition on the rays the host generator gives, and the cloud
+    rebuilt from nothing but the 4-byte triangle ids equals the compaction of the scan's own records, bit for bit --
+    ties, grazing hits and degenerate triangles included."""
+    import torch
+    import lidarcast
+    from lidarcast._capi import LrcCompactIO
+    from helpers import pose
+    global _CTX
+    try:
+        _CTX
+    except NameError:
+        _CTX = lidarcast.Context(0)
+    v, f, rays = scene
+    dirs = np.ascontiguousarray(rays[:192 if aligned else 200, 3:].astype(np.float64))   # 192 = 3 aligned tiles
+    rng = np.random.default_rng(len(v) * 7 + num_poses)
+    poses = np.stack([pose(*rng.choice(GRID, 3), yaw=float(rng.choice([0.0, 0.5, np.pi / 2, -2.0])))
+                      for _ in range(num_poses)])
+    P, N = len(poses), len(dirs)
+    sc = lidarcast.Scene(_CTX, v, f)
+    dev = torch.device("cuda", 0)
+    st_ = torch.cuda.current_stream().cuda_stream
+    want = ("t", "prim", "point3", "sem", "ins") + (("tile_count",) if aligned else ())
+    hits = lidarcast.DeviceHits(P * N, dev, want=want)
+    d_poses, d_dirs = torch.from_numpy(poses.reshape(P, 16)).to(dev), torch.from_numpy(dirs).to(dev)
+    sc.scan_poses_dev(d_poses, d_dirs, hits, 3.0, st_)
+    rows = torch.full((P * N, 4), 7.0, dtype=torch.float32, device=dev)
+    counts = torch.zeros(P, dtype=torch.int64, device=dev)
+    io = LrcCompactIO()
+    io.t, io.point3, io.sem, io.ins = (hits[a].data_ptr() for a in ("t", "point3", "sem", "ins"))
+    io.counts, io.out_xyzl = counts.data_ptr(), rows.data_ptr()
+    _CTX.compact_dev(P, N, io, st_)
+    rows2, counts2 = torch.full_like(rows, 7.0), torch.zeros_like(counts)
+    sc.cloud_from_prims_dev(d_poses, d_dirs, hits["prim"], rows2, counts2,
+                            tile_count_t=hits["tile_count"] if aligned else None, stream=st_)
+    torch.cuda.synchronize()
+    assert torch.equal(counts2, counts)
+    assert torch.equal(rows2.view(torch.int32), rows.view(torch.int32))
+    # and the scan itself against the definition, on the rays the host generator produces for these poses
+    om = OracleMesh(v, f)
+    t_gpu, prim_gpu = hits["t"].cpu().numpy().reshape(P, N), hits["prim"].cpu().numpy().view(np.uint32).reshape(P, N)
+    for p in range(P):
+        o = np.repeat(poses[p][:3, 3][None, :], N, 0).astype(np.float32)
+        d = np.dot(dirs, poses[p][:3, :3].T).astype(np.float32)
+        tb, pb = om.brute(np.concatenate([o, d], 1))
+        pts = o + (d / np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])[:, None]) * np.where(np.isfinite(tb), tb, 0)[:, None]
+        with np.errstate(invalid="ignore"):
+            keep = np.isfinite(tb) & (np.linalg.norm(pts.astype(np.float64) - poses[p][:3, 3], axis=1) < 3.0)
+        assert_bit_equal(t_gpu[p], np.where(keep, tb, np.inf).astype(np.float32))
+        assert_bit_equal(prim_gpu[p], np.where(keep, pb, 0xFFFFFFFF).astype(np.uint32))
+    sc.close()

@@ -64,6 +64,10 @@ typedef struct lrc_hits {
     uint32_t* tile_count;    /* (ceil(n/64)) DEVICE entry points only: number of kept entries in each
                                        aligned run of 64 outputs; lets lrc_compact_dev skip its counting
                                        pass (lrc_compact_io.tile_count).  Ignored by the host entry points */
+    float*    intensity;     /* (n)    opt-in (the reference computes no intensity; its noise model expects one
+                                       in [0,1], lidar/lidar_intrinsics.py:364-377): Lambertian return
+                                       |cos(angle between the ray and the unit geometric normal)|, float32;
+                                       0 on miss                                                        */
 } lrc_hits;
 
 typedef struct lrc_scene_info {

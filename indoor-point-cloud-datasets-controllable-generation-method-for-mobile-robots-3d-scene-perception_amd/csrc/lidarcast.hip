@@ -59,7 +59,7 @@ constexpr int kTBlock = LRC_TRACE_BLOCK;   // trace kernel workgroup (rays per t
 
 }  // namespace
 
-enum PoolSlot { kPoolRays = 0, kPoolT, kPoolPrim, kPoolNormal, kPoolPoint, kPoolSem, kPoolIns, kPoolInc,
+enum PoolSlot { kPoolRays = 0, kPoolT, kPoolPrim, kPoolNormal, kPoolPoint, kPoolSem, kPoolIns, kPoolInc, kPoolInten,
                 kPoolPoses, kPoolDirs, kPoolOffs, kPoolCen, kPoolNoise, kPoolSlots };
 
 #ifndef LRC_REBUILD_R
@@ -391,6 +391,7 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
     float nx = 0.f, ny = 0.f, nz = 0.f, px = 0.f, py = 0.f, pz = 0.f;
     uint32_t label = 0;
     double inc = 0.0;
+    float inten = 0.f;
     if (keep && p.range_noise) {
         // opt-in range noise (the reference declares range_noise_std but never applies it, lidar_intrinsics.py:
         // 364-389 has no caller): host-drawn additive noise on the range; a non-positive range drops the return
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
             t_out = tbest;
             prim = p.slot_prim[best_slot];
             label = p.slot_label[best_slot];
-            if (p.out.normal3 || (p.out.incident_deg && p.incident_mode == 1)) {
+            if (p.out.normal3 || p.out.intensity || (p.out.incident_deg && p.incident_mode == 1)) {
                 const float4 c = p.tris[(size_t)best_slot * 3 + 2];
                 const float len = __builtin_sqrtf(fma_(c.w, c.w, fma_(c.z, c.z, c.y * c.y)));
                 nx = c.y / len; ny = c.z / len; nz = c.w / len;
@@ -426,6 +427,8 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
                     inc = acos(__builtin_fabs(ez / dist)) * kRadToDeg;
                 }
             }
+            if (p.out.intensity)      // opt-in: Lambertian return |h.n|, float32 (same FMA order as every dot product here)
+                inten = __builtin_fabsf(fma_(hz, nz, fma_(hy, ny, hx * nx)));
             if (!p.out.normal3) { nx = ny = nz = 0.f; }
         } else {
             px = py = pz = 0.f;
@@ -444,6 +447,7 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
     if (p.out.sem) p.out.sem[gid] = (uint16_t)(label & 0xFFFFu);
     if (p.out.ins) p.out.ins[gid] = (uint16_t)(label >> 16);
     if (p.out.incident_deg) p.out.incident_deg[gid] = inc;
+    if (p.out.intensity) p.out.intensity[gid] = inten;
 
 }
 
@@ -981,7 +985,7 @@ struct DevBuf {
     }
 };
 struct HitsStage {
-    DevBuf t, prim, normal3, point3, sem, ins, inc;
+    DevBuf t, prim, normal3, point3, sem, ins, inc, inten;
     lrc_hits d{};
     int alloc(lrc_ctx* ctx, const lrc_hits& h, uint64_t n) {
         if (!n) return LRC_OK;
@@ -993,6 +997,7 @@ struct HitsStage {
         if (h.sem) { if ((rc = sem.get(ctx, kPoolSem, n * 2))) return rc; d.sem = (uint16_t*)sem.p; }
         if (h.ins) { if ((rc = ins.get(ctx, kPoolIns, n * 2))) return rc; d.ins = (uint16_t*)ins.p; }
         if (h.incident_deg) { if ((rc = inc.get(ctx, kPoolInc, n * 8))) return rc; d.incident_deg = (double*)inc.p; }
+        if (h.intensity) { if ((rc = inten.get(ctx, kPoolInten, n * 4))) return rc; d.intensity = (float*)inten.p; }
         return LRC_OK;
     }
     int download(const lrc_hits& h, uint64_t n) {
@@ -1004,6 +1009,7 @@ struct HitsStage {
         if (h.sem) LRC_HIP(hipMemcpy(h.sem, d.sem, n * 2, hipMemcpyDeviceToHost));
         if (h.ins) LRC_HIP(hipMemcpy(h.ins, d.ins, n * 2, hipMemcpyDeviceToHost));
         if (h.incident_deg) LRC_HIP(hipMemcpy(h.incident_deg, d.incident_deg, n * 8, hipMemcpyDeviceToHost));
+        if (h.intensity) LRC_HIP(hipMemcpy(h.intensity, d.intensity, n * 4, hipMemcpyDeviceToHost));
         return LRC_OK;
     }
 };

@@ -37,7 +37,8 @@ SYMBOLS = (
 class LrcHits(C.Structure):
     _fields_ = [("t", C.c_void_p), ("prim", C.c_void_p), ("normal3", C.c_void_p),
                 ("point3", C.c_void_p), ("sem", C.c_void_p), ("ins", C.c_void_p),
-                ("incident_deg", C.c_void_p), ("t_label", C.c_void_p), ("tile_count", C.c_void_p)]
+                ("incident_deg", C.c_void_p), ("t_label", C.c_void_p), ("tile_count", C.c_void_p),
+                ("intensity", C.c_void_p)]
 
 
 class LrcSceneInfo(C.Structure):

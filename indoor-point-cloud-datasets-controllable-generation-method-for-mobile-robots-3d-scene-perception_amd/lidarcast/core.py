@@ -18,7 +18,7 @@ ATTRS = ("t", "prim", "normal3", "point3", "sem", "ins", "incident_deg")
 _NP_SPEC = {
     "t": (np.float32, ()), "prim": (np.uint32, ()), "normal3": (np.float32, (3,)),
     "point3": (np.float32, (3,)), "sem": (np.uint16, ()), "ins": (np.uint16, ()),
-    "incident_deg": (np.float64, ()),
+    "incident_deg": (np.float64, ()), "intensity": (np.float32, ()),
 }
 
 
@@ -114,7 +114,7 @@ class DeviceHits:
 
     _TORCH = {"t": "float32", "prim": "int32", "normal3": "float32", "point3": "float32",
               "sem": "int16", "ins": "int16", "incident_deg": "float64", "tile_count": "int32",
-              "t_label": "int32"}
+              "t_label": "int32", "intensity": "float32"}
 
     def __init__(self, n, device, want=("t", "prim", "normal3", "point3", "sem", "ins")):
         import torch

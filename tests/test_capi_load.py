@@ -25,7 +25,17 @@ def test_header_and_library_agree():
 def test_struct_layouts_match_header():
     import ctypes as C
     from lidarcast._capi import LrcCompactIO, LrcHits, LrcSceneInfo
-    assert C.sizeof(LrcHits) == 9 * 8
+    from conftest import REPO
+
+    def header_fields(struct):
+        """member names of ``typedef struct <struct> { ... } <struct>;`` in include/lidarcast.h, in order"""
+        src = open(os.path.join(REPO, "include", "lidarcast.h")).read()
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), src, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return [re.search(r"(\w+)\s*(\[\d+\])?\s*$", decl.strip()).group(1) for decl in body.split(";") if decl.strip()]
+    assert [n for n, _ in LrcHits._fields_] == header_fields("lrc_hits")          # all pointers, same order
+    assert C.sizeof(LrcHits) == 10 * 8
+    assert [n for n, _ in LrcCompactIO._fields_] == header_fields("lrc_compact_io")
     assert C.sizeof(LrcCompactIO) == 13 * 8
     assert C.sizeof(LrcSceneInfo) == 5 * 8 + 2 * 4 + 8 + 2 * 8 + 6 * 4
 

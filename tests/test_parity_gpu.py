@@ -469,6 +469,35 @@ def test_simulator_workflows_write_the_reference_file_set(tmp_path):
     assert sim3.config["trajectory"]["robot_height"] == 0.8
 
 
+def test_opt_in_intensity(engine, a1):
+    """Row N4: lrc_hits.intensity = |h.n| in float32 (Lambertian return), 0 on a miss, and requesting it changes no
+    other output.  Restated with numpy from the engine's own normals and the rays' unit directions."""
+    mesh, _ = a1
+    k = sensor_small(lines=6, width=128, max_range=4.0)
+    lidar = __import__("lidar").create_lidar(k, pose(2.0, 3.0, 1.0, yaw=0.4))
+    rays = lidar.get_rays()
+    scene = engine.scene_for(mesh)
+    base = scene.cast(rays, center=lidar.pose[:3, 3], max_range=k.max_range, want=("t", "prim", "normal3", "point3"))
+    got = scene.cast(rays, center=lidar.pose[:3, 3], max_range=k.max_range,
+                     want=("t", "prim", "normal3", "point3", "intensity"))
+    for a in ("t", "prim", "normal3", "point3"):
+        assert_bit_equal(got[a], base[a], a)
+    only = scene.cast(rays, center=lidar.pose[:3, 3], max_range=k.max_range, want=("intensity",))
+    assert_bit_equal(only["intensity"], got["intensity"])
+    hit = np.isfinite(got["t"])
+    assert 0 < hit.sum() < len(rays)
+    d = rays[:, 3:]
+    h = d / np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])[:, None]
+    n = got["normal3"]
+    want = np.abs(np.float32(h[:, 2] * n[:, 2]) + (np.float32(h[:, 1] * n[:, 1]) + np.float32(h[:, 0] * n[:, 0])))
+    assert got["intensity"].dtype == np.float32 and (got["intensity"][~hit] == 0).all()
+    assert np.abs(got["intensity"][hit] - want[hit]).max() <= 2e-7          # fused vs unfused products
+    assert (got["intensity"] >= 0).all() and (got["intensity"] <= 1.0 + 1e-6).all()
+    poses = np.stack([lidar.pose, pose(2.5, 3.0, 1.0)])
+    rec, n_per = engine.scan_poses(k, poses, mesh, want=("t", "intensity"))
+    assert_bit_equal(rec["intensity"][0], got["intensity"])
+
+
 def test_in_kernel_rays_keep_the_sign_of_zero_components(ctx):
     """np.dot(directions, R.T) runs through dgemm, which accumulates from +0.0: a zero component of a rotated
     direction is +0.0 even when its only non-zero product is -0.0.  The in-kernel generator must give the same sign,

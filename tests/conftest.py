@@ -15,6 +15,13 @@ for p in (PKG, REPO):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A fresh checkout has no built libraries (they are git-ignored): build them the way the driver does
+    # (__graft_entry__.build(): hipcc for gfx950 + the oracle's Makefile).  A build error is fatal here, so a
+    # broken extension can never turn into skipped or quietly passing tests.
+    import __graft_entry__ as entry
+    deps = [os.path.join(entry.CSRC, f) for f in os.listdir(entry.CSRC)] + [os.path.join(REPO, "include", "lidarcast.h")]
+    if entry._stale(entry.LIB, deps):
+        entry.build()
 
 
 def _has_gpu():

@@ -606,6 +606,53 @@ def test_cloud_rebuilt_from_triangle_ids(ctx):
     scene.reset_options()
 
 
+def test_many_short_poses(ctx):
+    """A long trajectory of small scans (3 000 poses x 96 rays: more poses than threads in a workgroup, rays per pose
+    not a multiple of the wave size): per-pose counts, compaction and the rebuild from ids agree with numpy on the
+    host records; a sample of poses agrees with the host-ray path."""
+    import torch
+    import lidarcast
+    from lidarcast import synth
+    from lidarcast._capi import LrcCompactIO
+    from lidar import IndoorLidar
+    mesh = synth.make_room(size=(6, 4, 2.5), num_boxes=5, seed=8, cell=0.05)
+    scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
+    k = sensor_small(lines=3, width=32, max_range=2.5)
+    dirs = IndoorLidar(k, np.eye(4)).sensor_directions()
+    rng = np.random.default_rng(5)
+    P, N = 3000, len(dirs)
+    poses = np.stack([pose(*rng.uniform([0.5, 0.5, 0.5], [5.5, 3.5, 2.0]), yaw=float(rng.uniform(-3, 3))) for _ in range(P)])
+    host = scene.scan_poses(poses, dirs, k.max_range, want=("t", "prim", "point3", "sem", "ins"))
+    keep = np.isfinite(host["t"]).reshape(P, N)
+    assert 0.05 < keep.mean() < 0.95
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    hits = lidarcast.DeviceHits(P * N, dev, want=("t", "prim", "point3", "sem", "ins"))
+    d_poses, d_dirs = torch.from_numpy(poses.reshape(P, 16)).to(dev), torch.from_numpy(dirs).to(dev)
+    scene.scan_poses_dev(d_poses, d_dirs, hits, k.max_range, st)
+    rows = torch.full((P * N, 4), 7.0, dtype=torch.float32, device=dev)
+    counts = torch.zeros(P, dtype=torch.int64, device=dev)
+    io = LrcCompactIO()
+    io.t, io.point3, io.sem, io.ins = (hits[a].data_ptr() for a in ("t", "point3", "sem", "ins"))
+    io.counts, io.out_xyzl = counts.data_ptr(), rows.data_ptr()
+    ctx.compact_dev(P, N, io, st)
+    rows2, counts2 = torch.full_like(rows, 7.0), torch.zeros_like(counts)
+    scene.cloud_from_prims_dev(d_poses, d_dirs, hits["prim"], rows2, counts2, stream=st)
+    torch.cuda.synchronize()
+    assert np.array_equal(counts.cpu().numpy(), keep.sum(1)) and torch.equal(counts2, counts)
+    K = int(keep.sum())
+    got = rows.cpu().numpy()
+    assert_bit_equal(got[:K, :3], host["point3"][keep.reshape(-1)])
+    lab = host["sem"][keep.reshape(-1)].astype(np.uint32) | (host["ins"][keep.reshape(-1)].astype(np.uint32) << 16)
+    assert np.array_equal(got[:K, 3].copy().view(np.uint32), lab) and (got[K:] == 7.0).all()
+    assert torch.equal(rows2.view(torch.int32), rows.view(torch.int32))
+    for p in (0, 1, 255, 256, 257, 1023, 2999):
+        ref = scene.cast(IndoorLidar(k, poses[p]).get_rays(), center=poses[p][:3, 3], max_range=k.max_range,
+                         want=("t", "prim"))
+        assert_bit_equal(host["t"].reshape(P, N)[p], ref["t"], f"pose {p}")
+        assert_bit_equal(host["prim"].reshape(P, N)[p], ref["prim"], f"pose {p}")
+
+
 def test_full_size_c3_properties(ctx):
     """BASELINE config C3 at full size (64 poses x 65 536 rays, T = 605 328), device-resident path.
     Size-independent properties + four poses checked ray by ray against the oracle."""

@@ -243,7 +243,10 @@ int lrc_cloud_from_ranges_dev(lrc_ctx* ctx, const double* d_poses16, uint64_t nu
  *                  same slabs: tile k of slab r at d_tile_count[r * slab_stride_bytes/4 + k].  Saves the counting
  *                  pass; needs rays_per_pose % 64 == 0
  *   ranks that own fewer poses than poses_per_slab pad their slab with LRC_INVALID_PRIM entries (zero counts); the
- *   pose table then has num_poses = slabs * poses_per_slab rows, padded ones arbitrary. */
+ *   pose table then has num_poses = slabs * poses_per_slab rows, padded ones arbitrary.
+ * Scratch (tile offsets, transposed direction table) belongs to the scene's context: lrc_cloud_from_prims_dev and
+ * lrc_cloud_from_ranges_dev share one set, lrc_compact_dev has its own, so a rebuild may run on one stream beside a
+ * compaction on another, but two rebuilds (or two compactions) of one context must not overlap in time. */
 int lrc_cloud_from_prims_dev(lrc_scene* scene, const double* d_poses16, uint64_t num_poses,
                              const double* d_dirs3, uint64_t rays_per_pose, const uint32_t* d_prim,
                              const uint32_t* d_tile_count, uint64_t poses_per_slab, uint64_t slab_stride_bytes,

@@ -606,6 +606,21 @@ def test_cloud_rebuilt_from_triangle_ids(ctx):
     scene.reset_options()
 
 
+def test_examples_run(tmp_path):
+    """examples/ are part of the documentation: they must run as written."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "examples", "drop_in_engine.py")], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "lidar_intersect_mesh:" in r.stdout and "bad input -> ValueError" in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(REPO, "examples", "simulate_room.py"), "--out",
+                        str(tmp_path / "out"), "--waypoints", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "combined_pointcloud_with_label.ply" in r.stdout and "planned" in r.stdout
+
+
 def test_many_short_poses(ctx):
     """A long trajectory of small scans (3 000 poses x 96 rays: more poses than threads in a workgroup, rays per pose
     not a multiple of the wave size): per-pose counts, compaction and the rebuild from ids agree with numpy on the

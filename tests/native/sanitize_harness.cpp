@@ -1,0 +1,38 @@
+// Sanitizer harness (CPU only; GPU AddressSanitizer is not available on the pool): the host BVH builder of the product
+// (csrc/bvh_build.cpp, threaded) and the C oracle, on random, snapped, single-point and tiny meshes, under
+// -fsanitize=address,undefined.  Built and run by tests/test_native_sanitizers.py.
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#include <cmath>
+#include "lrc_bvh.h"
+extern "C" {
+void orc_cast_brute(const float*, const uint32_t*, uint64_t, const float*, uint64_t, float*, uint32_t*);
+struct orc_bvh; orc_bvh* orc_bvh_build(const float*, const uint32_t*, uint64_t); void orc_bvh_free(orc_bvh*);
+void orc_cast_bvh(const orc_bvh*, const float*, uint64_t, float*, uint32_t*, int);
+}
+static float rnd() { return (float)rand() / RAND_MAX; }
+int main() {
+    for (int round = 0; round < 6; ++round) {
+        uint64_t T = round == 0 ? 1 : round == 1 ? 5 : round == 2 ? 1000 : round == 3 ? 50000 : round == 4 ? 7 : 200000;
+        std::vector<float> v(T * 9);
+        std::vector<uint32_t> f(T * 3);
+        for (uint64_t i = 0; i < T * 9; ++i) v[i] = (round == 4) ? 0.5f : (round % 2 ? std::floor(rnd() * 8) / 4 : rnd() * 4);
+        for (uint64_t i = 0; i < T * 3; ++i) f[i] = (uint32_t)i;
+        lrc::HostBVH h; lrc::BuildOptions opt; opt.threads = 4;
+        lrc::build_bvh(v.data(), T * 3, f.data(), T, nullptr, nullptr, opt, &h);
+        uint64_t N = 2000;
+        std::vector<float> rays(N * 6), t1(N), t2(N); std::vector<uint32_t> p1(N), p2(N);
+        for (uint64_t i = 0; i < N * 6; ++i) rays[i] = rnd() * 4 - (i % 6 >= 3 ? 2 : 0);
+        orc_bvh* b = orc_bvh_build(v.data(), f.data(), T);
+        orc_cast_bvh(b, rays.data(), N, t2.data(), p2.data(), 3);
+        if (T <= 50000) {
+            orc_cast_brute(v.data(), f.data(), T, rays.data(), N, t1.data(), p1.data());
+            for (uint64_t i = 0; i < N; ++i) if (p1[i] != p2[i]) { printf("MISMATCH round %d ray %lu\n", round, (unsigned long)i); return 1; }
+        }
+        orc_bvh_free(b);
+        printf("round %d T=%lu nodes=%lu depth=%u ok\n", round, (unsigned long)T, (unsigned long)h.num_nodes, h.max_depth);
+    }
+    return 0;
+}

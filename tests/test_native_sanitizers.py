@@ -1,0 +1,26 @@
+"""AddressSanitizer + UndefinedBehaviorSanitizer over the host-side native code (the threaded SAH builder of the
+product and the C oracle), CPU build only."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import PKG, REPO
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_builder_and_oracle_under_asan_ubsan(tmp_path):
+    csrc = os.path.join(PKG, "csrc")
+    flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
+    obj = tmp_path / "orc.o"
+    subprocess.run(["gcc", *flags, "-ffp-contract=off", "-c", os.path.join(REPO, "oracle", "lrc_oracle.c"), "-o", str(obj)],
+                   check=True, capture_output=True, text=True)
+    exe = tmp_path / "harness"
+    subprocess.run(["g++", "-std=c++17", *flags, "-I", csrc, os.path.join(REPO, "tests", "native", "sanitize_harness.cpp"),
+                    os.path.join(csrc, "bvh_build.cpp"), str(obj), "-o", str(exe), "-pthread", "-lm"],
+                   check=True, capture_output=True, text=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-3000:])
+    assert r.stdout.count(" ok") == 6 and "MISMATCH" not in r.stdout and "runtime error" not in r.stderr

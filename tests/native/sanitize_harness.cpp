@@ -22,6 +22,14 @@ int main() {
         for (uint64_t i = 0; i < T * 3; ++i) f[i] = (uint32_t)i;
         lrc::HostBVH h; lrc::BuildOptions opt; opt.threads = 4;
         lrc::build_bvh(v.data(), T * 3, f.data(), T, nullptr, nullptr, opt, &h);
+        for (int threads : {1, 16}) {     // the layout must not depend on how many tasks built it (every rank of a
+            lrc::HostBVH g; lrc::BuildOptions o2; o2.threads = threads;      // multi-GPU job builds its own replica)
+            lrc::build_bvh(v.data(), T * 3, f.data(), T, nullptr, nullptr, o2, &g);
+            if (g.nodes != h.nodes || g.tri_rec != h.tri_rec || g.slot_prim != h.slot_prim || g.max_depth != h.max_depth) {
+                printf("NONDETERMINISTIC round %d threads %d\n", round, threads);
+                return 2;
+            }
+        }
         uint64_t N = 2000;
         std::vector<float> rays(N * 6), t1(N), t2(N); std::vector<uint32_t> p1(N), p2(N);
         for (uint64_t i = 0; i < N * 6; ++i) rays[i] = rnd() * 4 - (i % 6 >= 3 ? 2 : 0);

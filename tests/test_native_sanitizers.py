@@ -1,5 +1,6 @@
 """AddressSanitizer + UndefinedBehaviorSanitizer over the host-side native code (the threaded SAH builder of the
-product and the C oracle), CPU build only."""
+product and the C oracle), CPU build only; the same harness checks that the builder's output is byte-identical for
+1, 4 and 16 build threads and that the oracle's BVH equals its brute force."""
 import os
 import shutil
 import subprocess
@@ -23,4 +24,5 @@ def test_builder_and_oracle_under_asan_ubsan(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-3000:])
-    assert r.stdout.count(" ok") == 6 and "MISMATCH" not in r.stdout and "runtime error" not in r.stderr
+    assert r.stdout.count(" ok") == 6 and "MISMATCH" not in r.stdout and "NONDETERMINISTIC" not in r.stdout
+    assert "runtime error" not in r.stderr

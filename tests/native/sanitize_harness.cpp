@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <vector>
 #include <cmath>
+#include <cstring>
 #include "lrc_bvh.h"
 extern "C" {
 void orc_cast_brute(const float*, const uint32_t*, uint64_t, const float*, uint64_t, float*, uint32_t*);
@@ -25,7 +26,11 @@ int main() {
         for (int threads : {1, 16}) {     // the layout must not depend on how many tasks built it (every rank of a
             lrc::HostBVH g; lrc::BuildOptions o2; o2.threads = threads;      // multi-GPU job builds its own replica)
             lrc::build_bvh(v.data(), T * 3, f.data(), T, nullptr, nullptr, o2, &g);
-            if (g.nodes != h.nodes || g.tri_rec != h.tri_rec || g.slot_prim != h.slot_prim || g.max_depth != h.max_depth) {
+            auto same = [](const std::vector<float>& a, const std::vector<float>& b) {   // bytes: child refs are ints
+                return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0;
+            };
+            if (!same(g.nodes, h.nodes) || !same(g.tri_rec, h.tri_rec) || g.slot_prim != h.slot_prim ||
+                g.max_depth != h.max_depth) {
                 printf("NONDETERMINISTIC round %d threads %d\n", round, threads);
                 return 2;
             }

@@ -10,9 +10,8 @@ Differences from the reference, all on purpose:
   * the labelled PLY is written with one structured-array ``tofile`` instead of a per-point
     ``struct.pack`` loop; header and record layout are byte-identical (:619-641);
   * ``combined_pointcloud.ply`` is written by this package's own PLY writer (the reference hands it to Open3D);
-  * the S3DIS annotation file loaders are out of scope: the ``_load_s3dis_*`` hooks try the
-    reference's ``s3dis_annotation_loader`` module if the caller has it on the path and otherwise report "no data",
-    which is exactly what the reference's own try/except does when the module is missing.
+  * the ``_load_s3dis_*`` hooks read the annotation files through this package's ``s3dis_annotation_loader`` (same
+    names and results as the reference's module) and, like the reference, report "no data" on any failure.
 """
 import json
 import os
@@ -388,7 +387,7 @@ class S3DISSimScene:
         return None, None
 
     def _annotation_arrays(self):
-        from s3dis_annotation_loader import S3DISAnnotationLoader    # the caller's module, if present
+        from s3dis_annotation_loader import S3DISAnnotationLoader
         loader = S3DISAnnotationLoader(self.s3dis_data_root)
         rooms = loader.load_room_annotations(self.area, self.room)
         if not rooms:

@@ -963,3 +963,47 @@ def test_kernel_variants_are_bit_identical():
         digests[name] = r.stdout.strip().splitlines()[-1]
     assert len(set(digests.values())) == 1, digests
     assert int(digests["default"].split()[1]) > 30000 and int(digests["default"].split()[2]) > 1000
+
+
+def test_export_labels_from_annotation_files(tmp_path, engine):
+    """The whole label path from files on disk, as the reference wires it: S3DISSimScene(s3dis_data_root, area, room)
+    -> s3dis_annotation_loader (Annotations/<class>_<k>.txt) -> raw coloured cloud <room>.txt -> nearest annotated point
+    per hit point -> labelled PLY.  Checked against the same steps done with numpy + sklearn."""
+    from sklearn.neighbors import NearestNeighbors
+    from containers import S3DISSimFrame, S3DISSimScene, ScanQuality, read_labeled_ply
+    from lidarcast import synth
+    from s3dis_annotation_loader import S3DISAnnotationLoader
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=2, seed=3, cell=0.08)
+    rng = np.random.default_rng(1)
+    room = tmp_path / "data" / "Area_7" / "office_3"
+    (room / "Annotations").mkdir(parents=True)
+    raw = []
+    for name, n in (("wall_1", 4000), ("floor_1", 2500), ("chair_1", 800), ("table_1", 900), ("ceiling_1", 2000)):
+        tri = mesh.triangles[rng.integers(0, len(mesh.triangles), n)]
+        w = rng.dirichlet([1, 1, 1], n)
+        pts = (mesh.vertices[tri] * w[:, :, None]).sum(1)
+        rgb = rng.integers(0, 256, (n, 3))
+        np.savetxt(room / "Annotations" / f"{name}.txt", np.hstack([pts, rgb]), fmt="%.6f %.6f %.6f %d %d %d")
+        raw.append(np.hstack([pts, rgb]))
+    np.savetxt(room / "office_3.txt", np.vstack(raw), fmt="%.6f %.6f %.6f %d %d %d")
+    k = sensor_small(lines=6, width=128, max_range=20.0)
+    rec, _ = engine.scan_poses(k, np.stack([pose(1.5, 1.5, 1.0), pose(2.5, 1.5, 1.2)]), mesh, want=("t", "point3"))
+    sc = S3DISSimScene("office_3", s3dis_data_root=str(tmp_path / "data"), area="Area_7", room="office_3")
+    q = ScanQuality(0, 0, 0, 0, 0, 0, 0)
+    for i in range(2):
+        pts = rec["point3"][i][np.isfinite(rec["t"][i])]
+        sc.append_frame(S3DISSimFrame(i, pts, np.zeros(len(pts)), q))
+    sc._export_combined_pointcloud_with_labels(tmp_path)
+    out = read_labeled_ply(tmp_path / "combined_pointcloud_with_label.ply")
+    # the same with the loader + sklearn
+    loader = S3DISAnnotationLoader(str(tmp_path / "data"))
+    ap, al, ai = loader.create_labeled_pointcloud_with_instances(loader.load_room_annotations("Area_7", "office_3"))
+    assert len(ap) == 10200 and set(np.unique(al)) == {0, 1, 2, 7, 8}
+    rawd = np.loadtxt(room / "office_3.txt")
+    col = rawd[NearestNeighbors(n_neighbors=1, algorithm="ball_tree").fit(rawd[:, :3]).kneighbors(ap)[1][:, 0], 3:6] / 255.0
+    allp = sc.combined_points()
+    j = NearestNeighbors(n_neighbors=1, algorithm="ball_tree").fit(ap).kneighbors(allp)[1][:, 0]
+    assert len(out) == len(allp) > 500
+    assert np.array_equal(out["sem"], al[j].astype(np.uint16)) and np.array_equal(out["ins"], ai[j].astype(np.uint16))
+    assert np.array_equal(np.stack([out["red"], out["green"], out["blue"]], 1), (col[j] * 255).astype(np.uint8))
+

@@ -4,12 +4,12 @@
 // open3d RaycastingScene.add_triangles (reference: raycast_engine/raycast_engine_cpu.py:46-47),
 // which the reference repeats for every pose (raycast_engine/raycast_engine.py:20-24).
 //
-// Properties the traversal kernels rely on (tests/test_bvh.py checks them on exported trees):
+// Properties the traversal kernels rely on (tests/test_parity_gpu.py::test_bvh_invariants checks them on exported trees):
 //   * every triangle sits in exactly one leaf slot; leaves hold 1..max_leaf triangles;
 //   * a child box is the EXACT float32 min/max of the vertices below it (no arithmetic, no padding),
 //     so computed slab intervals nest ("why any BVH gives the same hits");
 //   * leaf depth <= 31, so a 32-entry traversal stack can never overflow;
-//   * the first `bfs_nodes` nodes are in breadth-first order (top of tree contiguous, staged in LDS),
+//   * the first `bfs_nodes` nodes are in breadth-first order (top of tree contiguous: the part every wave walks, fetched through the scalar cache),
 //     the rest in depth-first order (a subtree is contiguous in HBM);
 //   * deterministic for a given input.
 #include "lrc_bvh.h"

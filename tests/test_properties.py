@@ -123,8 +123,8 @@ def test_cloud_rebuilt_from_ids_on_adversarial_scenes(scene, num_poses, aligned)
         o = np.repeat(poses[p][:3, 3][None, :], N, 0).astype(np.float32)
         d = np.dot(dirs, poses[p][:3, :3].T).astype(np.float32)
         tb, pb = om.brute(np.concatenate([o, d], 1))
-        pts = o + (d / np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])[:, None]) * np.where(np.isfinite(tb), tb, 0)[:, None]
-        with np.errstate(invalid="ignore"):
+        with np.errstate(invalid="ignore", divide="ignore"):      # hypothesis also draws zero-length directions
+            pts = o + (d / np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])[:, None]) * np.where(np.isfinite(tb), tb, 0)[:, None]
             keep = np.isfinite(tb) & (np.linalg.norm(pts.astype(np.float64) - poses[p][:3, 3], axis=1) < 3.0)
         assert_bit_equal(t_gpu[p], np.where(keep, tb, np.inf).astype(np.float32))
         assert_bit_equal(prim_gpu[p], np.where(keep, pb, 0xFFFFFFFF).astype(np.uint32))

@@ -3,6 +3,7 @@
 # PMC_ARGS overrides the bench.py arguments (e.g. "--dist-selftest --virtual-world 8 ..." for the rebuild kernel).
 # Counters are collected in their own runs (no tracing domains besides --kernel-trace), one group per pass.
 set -u
+FAILED=0
 TAG=${1:-pmc}
 PAT=${2:-trace_kernel}
 ARGS=${PMC_ARGS:---steps 3 --warmup 1 --no-cpu-baseline}
@@ -20,7 +21,8 @@ for grp in \
   "FETCH_SIZE" \
   "WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" ; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 $R/bench.py $ARGS > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 $R/bench.py $ARGS > $OUT/p$i.log 2>&1 || { echo "pass $i FAILED: $grp"; FAILED=1; }
 done
 python3 $R/tools/pmc_summary.py $OUT $PAT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+if [ $FAILED -ne 0 ]; then echo "pmc.sh: at least one counter pass failed (see p*.log)"; exit 1; fi

@@ -17,6 +17,9 @@
  *     (synchronous on return).  "_dev" entry points take DEVICE pointers and a hipStream_t
  *     (passed as void*; NULL = the null stream) and only enqueue work.
  *   - handles are not thread-safe; use one context per thread.
+ *   - finite-ray contract: a ray with a NaN or infinite origin or direction component is never cast; it is reported
+ *     as a miss (t = +inf, prim = LRC_INVALID_PRIM, zeros elsewhere), as Embree reports a ray it cannot intersect.
+ *     Mesh vertices must be finite and within 1e6 (lrc_scene_create rejects others).
  *
  * Hit definition (oracle/lrc_oracle.c restates it on the CPU)
  *   Two-sided closest hit, t in (0, +inf), t parametric along the GIVEN direction (the direction
@@ -189,12 +192,70 @@ typedef struct lrc_compact_io {
     uint32_t*       out_index;
     float*          out_xyzl;      /* (K,4) packed rows x, y, z, label bits (sem | ins<<16): the 16-byte
                                       row the multi-GPU all-gather moves                              */
+    float*          out_range_origin; /* (K) |point| from the WORLD origin in float32, formed as numpy's
+                                      np.linalg.norm(points, axis=1) forms it: the quantity the reference takes its
+                                      ScanQuality range statistics over (s3dis_simulator.py:283-284)  */
 } lrc_compact_io;
 
 int lrc_compact(lrc_ctx* ctx, uint64_t num_segments, uint64_t seg_len,
                 const lrc_compact_io* io, uint64_t* out_total);
 int lrc_compact_dev(lrc_ctx* ctx, uint64_t num_segments, uint64_t seg_len,
                     const lrc_compact_io* d_io, void* stream);
+
+/* ---- scan straight to the reference's variable-length frames ---------------------------------------
+ * What S3DISSimulator.run_simulation needs from a whole trajectory (s3dis_simulator.py:254-288): per pose the kept
+ * points and their attributes, in ray order.  One call = pose-batched scan (lrc_scan_poses_dev) + stable compaction
+ * (lrc_compact_dev) in HBM + the per-pose counts + ONE transfer per requested array of exactly the K kept rows.
+ * Frame p is rows [sum(counts[:p]), sum(counts[:p+1])) of every array: np.vstack order
+ * (containers/s3dis_sim_scene.py:326).  All pointers are HOST pointers the caller allocated, `capacity` rows each
+ * (num_poses * rays_per_pose always suffices; a smaller buffer fails with LRC_ERR_INVALID_ARG and *out_total = K, so
+ * that the caller can retry).  counts is required, every other array may be NULL.  Buffers from lrc_host_alloc are
+ * page-locked: the transfers then run as DMA at PCIe rate instead of through the runtime's staging copies. */
+typedef struct lrc_frames {
+    uint64_t* counts;        /* (num_poses) kept rays per pose                                       */
+    float*    point3;        /* (K,3)                                                                */
+    uint16_t* sem;           /* (K)                                                                  */
+    uint16_t* ins;           /* (K)                                                                  */
+    double*   incident_deg;  /* (K)                                                                  */
+    uint32_t* index;         /* (K) index of the kept ray inside its pose (the surviving-ray list)   */
+    float*    xyzl;          /* (K,4) x, y, z, label bits (sem | ins<<16)                            */
+    float*    range_origin;  /* (K) see lrc_compact_io.out_range_origin                              */
+} lrc_frames;
+int lrc_scan_poses_compact(lrc_scene* scene, const double* poses16, uint64_t num_poses,
+                           const double* dirs3, uint64_t rays_per_pose, double max_range,
+                           const lrc_frames* out, uint64_t capacity, uint64_t* out_total);
+
+/* Page-locked host memory for the frame buffers above (hipHostMalloc / hipHostFree).  The caller owns it. */
+int lrc_host_alloc(lrc_ctx* ctx, uint64_t bytes, void** out_ptr);
+int lrc_host_free(lrc_ctx* ctx, void* ptr);
+
+/* ---- dual-axis sensor: rays generated in the kernel from host-drawn scan angles (opt-in) ---------------
+ * The reference's DualAxisLidar draws, per ray, a noisy azimuth phi and elevation theta from the global numpy stream
+ * and drops ~2 % of the rays with one more uniform draw (lidar/indoor_lidar.py:262-294); that stream is what "seeded
+ * identically" means, so the draws stay on the host.  What moves to the device is everything after them: sin/cos,
+ * the rotation into the world frame (un-fused, as numpy evaluates it, :283-287) and the float32 narrowing.
+ *   angles2 : (num_poses * rays_per_pose, 2) float64 (phi, theta), pose-major
+ *   keep    : nullable (num_poses * rays_per_pose) bytes, 0 = ray dropped by the sensor: never cast, reported as a
+ *             miss, so the compacted frames equal those of casting only the kept rays
+ * Output index = p * rays_per_pose + i; range filter centre = pose[:3,3].  NOT bit-guaranteed against the host
+ * generator: the device's double-precision sin/cos need not round like the host's libm (the tests count the rays
+ * whose float32 direction differs).  The default path (host generator + lrc_cast_segments) stays bit-exact. */
+int lrc_scan_angles_dev(lrc_scene* scene, const double* d_poses16, uint64_t num_poses, const double* d_angles2,
+                        const uint8_t* d_keep, uint64_t rays_per_pose, double max_range, const lrc_hits* d_out,
+                        void* stream);
+int lrc_scan_angles_compact(lrc_scene* scene, const double* poses16, uint64_t num_poses, const double* angles2,
+                            const uint8_t* keep, uint64_t rays_per_pose, double max_range, const lrc_frames* out,
+                            uint64_t capacity, uint64_t* out_total);
+
+/* ---- diagnostics ---------------------------------------------------------------------------------------
+ * Per-ray traversal counters of a pose-batched scan from an instrumented build of the trace kernel, host arrays.
+ * stats: (num_poses * rays_per_pose, LRC_STATS_WORDS) uint32: [0] inner-node steps, [1] triangle tests, [2] node steps
+ * taken wave-uniformly (scalar fetch), [3] node steps with no child hit, [4] triangles that pass every
+ * Moeller-Trumbore condition and are rejected only by the hit definition's box clause -- the one
+ * clause Embree does not have; the tests assert a total of 0 on the BASELINE configurations. */
+#define LRC_STATS_WORDS 5
+int lrc_debug_scan_stats(lrc_scene* scene, const double* poses16, uint64_t num_poses, const double* dirs3,
+                         uint64_t rays_per_pose, double max_range, uint32_t* stats);
 
 /* ---- opt-in sensor-realism options --------------------------------
  * The reference DECLARES these sensor parameters but never applies them (SURVEY.md F6, F7:

@@ -255,17 +255,21 @@ class S3DISSimScene:
         return (np.ones((num_points, 3), dtype=np.float32) * 0.5, np.zeros(num_points, dtype=np.uint16),
                 np.zeros(num_points, dtype=np.uint16))
 
-    def _get_colors_and_labels_from_s3dis(self, points: np.ndarray):
-        """Nearest annotated point per hit point -> (colors, semantic, instance); defaults without a cloud.
-        Same contract as the reference method of this name (:379-427); the ball-tree query is the GPU 1-NN."""
+    def _ensure_annotations(self):
+        """The reference's lazy load of the room's annotation files (:392-409), tried once per scene, when
+        s3dis_data_root / area / room are configured and no cloud was attached by hand."""
         if (self._annotated is None and self._s3dis_cache is None and self.s3dis_data_root and self.area
                 and self.room):
-            # the reference's lazy load through the caller's annotation loader (:392-409), tried once
             self._s3dis_cache = {}
             pts, cols, sem, ins = self._load_s3dis_annotations_with_colors()
             if pts is not None and len(pts) > 0:
                 self.set_annotated_cloud(pts, cols, sem, ins)
                 self._s3dis_cache = {"points": pts, "colors": cols, "labels": sem, "instances": ins}
+
+    def _get_colors_and_labels_from_s3dis(self, points: np.ndarray):
+        """Nearest annotated point per hit point -> (colors, semantic, instance); defaults without a cloud.
+        Same contract as the reference method of this name (:379-427); the ball-tree query is the GPU 1-NN."""
+        self._ensure_annotations()
         if self._annotated is None or len(points) == 0:
             return self._get_default_colors_and_labels(len(points))
         if self._nn is None:
@@ -343,6 +347,9 @@ class S3DISSimScene:
         if len(pts) == 0:
             return
         has_frame_labels = any(f.semantic_labels is not None for f in self.frames if len(f.points) > 0)
+        # With the annotation source configured (the reference's normal wiring, :379-427) the files decide colours and
+        # labels, also when the frames carry the hit triangles' labels: load them before choosing the branch.
+        self._ensure_annotations()
         if self._annotated is not None or not has_frame_labels:
             # the reference's path: per frame, colours and labels of the nearest annotated point, or its defaults
             cols, sems, inss = [], [], []

@@ -60,7 +60,10 @@ constexpr int kTBlock = LRC_TRACE_BLOCK;   // trace kernel workgroup (rays per t
 }  // namespace
 
 enum PoolSlot { kPoolRays = 0, kPoolT, kPoolPrim, kPoolNormal, kPoolPoint, kPoolSem, kPoolIns, kPoolInc, kPoolInten,
-                kPoolPoses, kPoolDirs, kPoolOffs, kPoolCen, kPoolNoise, kPoolSlots };
+                kPoolPoses, kPoolDirs, kPoolOffs, kPoolCen, kPoolNoise,
+                // *_compact entry points: scan angles in, per-wave keep counts, compacted frame arrays out
+                kPoolAngles, kPoolKeep, kPoolTile, kPoolCounts, kPoolOutPoint, kPoolOutSem, kPoolOutIns, kPoolOutInc,
+                kPoolOutIdx, kPoolOutXyzl, kPoolOutRange, kPoolStats, kPoolSlots };
 
 #ifndef LRC_REBUILD_R
 #define LRC_REBUILD_R 2      // tiles (of 64 entries) one wave of the cloud rebuild handles (1, 2, 4, 8 measured equal)
@@ -130,8 +133,11 @@ struct TraceParams {
     const uint64_t* seg_offsets;   // explicit rays in S segments (poses): (S+1) ray offsets, or NULL
     const double* seg_centers3;    // (S,3) range-filter centres of the segments
     uint32_t num_segments;
-    const double* poses16;     // GEN = true
-    const double* dirs3;       // GEN = true
+    const double* poses16;     // GEN = 1, 2
+    const double* dirs3;       // GEN = 1: (N,3) sensor-frame direction table
+    const double* angles2;     // GEN = 2: (P*N,2) noisy (phi, theta) of the dual-axis sensor
+    const uint8_t* keep_mask;  // GEN = 2, nullable: 0 = ray dropped by the sensor (never cast, reported as a miss)
+    uint32_t* stats;           // STATS build only: kStatsWords counters per ray
     uint64_t rays_per_pose;
     uint64_t total;
     int has_center;
@@ -242,7 +248,10 @@ __device__ __forceinline__ void rebuild_counts(const RebuildParams& q, uint32_t 
     }
 }
 
-template <bool GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false>
+constexpr int kStatsWords = 5;   // node steps, triangle tests, wave-uniform node steps, dead node steps, pad-clause rejections
+
+// GEN: 0 = explicit rays, 1 = pose x direction table, 2 = pose x per-ray scan angles (dual-axis sensor, opt-in)
+template <int GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false>
 __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
     extern __shared__ int s_stack[];   // [stack depth][kTBlock]: one column per lane, conflict free
     const uint32_t tid = threadIdx.x;
@@ -252,10 +261,16 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
     // ---- the ray ----
     V3 o, d;
     double cx, cy, cz;
-    if (GEN) {
+    bool live = true;          // false: not cast at all (dropped by the sensor, or a non-finite ray)
+    if (GEN == 1) {
         const uint64_t pose = gid / p.rays_per_pose;
         const uint64_t i = gid - pose * p.rays_per_pose;
         gen_ray(p.poses16, p.dirs3, pose, i, o, d, cx, cy, cz);
+    } else if (GEN == 2) {
+        const uint64_t pose = gid / p.rays_per_pose;
+        const double2 a = ((const double2*)p.angles2)[gid];
+        gen_ray_angles(p.poses16, pose, a.x, a.y, o, d, cx, cy, cz);
+        if (p.keep_mask) live = p.keep_mask[gid] != 0;
     } else {
         const float* r = p.rays6 + gid * 6;
         o.x = r[0]; o.y = r[1]; o.z = r[2];
@@ -279,14 +294,15 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
     uint32_t best_slot = 0xFFFFFFFFu;
     uint32_t best_prim = 0xFFFFFFFFu;   // loaded lazily, only to break exact ties
 
-    float st_nodes = 0.f, st_tris = 0.f, st_uni = 0.f, st_dead = 0.f;   // STATS build only (tools/trav_stats.py)
-    if (p.num_nodes) {
+    uint32_t st_nodes = 0, st_tris = 0, st_uni = 0, st_dead = 0, st_pad = 0;   // STATS build only (lrc_debug_scan_stats)
+    live = live & finite_ray(o, d);
+    if (p.num_nodes && live) {
         int sp = 0;
         int ref = 0;   // root
         // one inner-node step: test both child boxes, descend into the nearer hit child, push the other;
         // nothing hit -> pop, or (stack empty) continue with the empty leaf so that the outer loop ends
         auto step = [&](const F4 q0, const F4 q1, const F4 q2, const F4 q3) {
-            if (STATS) st_nodes += 1.0f;
+            if (STATS) st_nodes += 1u;
             float n0, f0, n1, f1;
             slab_interval(sl, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, n0, f0);
             slab_interval(sl, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, n1, f1);
@@ -303,10 +319,10 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
             } else if (h1) {
                 ref = r1;
             } else if (sp == 0) {
-                if (STATS) st_dead += 1.0f;
+                if (STATS) st_dead += 1u;
                 ref = ~0;   // empty leaf
             } else {
-                if (STATS) st_dead += 1.0f;
+                if (STATS) st_dead += 1u;
                 --sp;
                 ref = s_stack[sp * kTBlock + tid];
             }
@@ -327,12 +343,12 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
 #pragma unroll
                 for (int j = 0; j < LEAFW; ++j) {
                     if (k0 + j < cnt) {
-                        if (STATS) st_tris += 1.0f;
+                        if (STATS) st_tris += 1u;
                         const uint32_t slot = first + k0 + j;
                         const float4 a = ra[j], b = rb[j], c = rc[j];
                         const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
                         float t;
-                        if (tri_hit(o, d, sl, v0, v1, v2, ng, t)) {
+                        if (tri_hit<STATS>(o, d, sl, v0, v1, v2, ng, t, &st_pad)) {
                             if (t < tbest) {
                                 tbest = t; best_slot = slot; best_prim = 0xFFFFFFFFu;
                             } else if (t == tbest) {
@@ -355,7 +371,7 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
                     // SGPRs (s_load) instead of 64 identical 64-byte vector loads through the L1.
                     const int uref = __builtin_amdgcn_readfirstlane(ref);
                     if (__builtin_amdgcn_ballot_w64(ref != uref) == 0ull) {
-                        if (STATS) st_uni += 1.0f;
+                        if (STATS) st_uni += 1u;
                         const float4* n = p.nodes + (size_t)uref * 4;
                         step(ld_uniform(n), ld_uniform(n + 1), ld_uniform(n + 2), ld_uniform(n + 3));
                     } else {
@@ -407,7 +423,7 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
         // range filter + incident angle in float64 (raycast_engine_cpu.py:95-107)
         const double ex = (double)px - cx, ey = (double)py - cy, ez = (double)pz - cz;
         const double dist = __builtin_sqrt((ex * ex + ey * ey) + ez * ez);
-        if (p.has_center || GEN) keep = dist < p.max_range;
+        if (p.has_center || GEN != 0) keep = dist < p.max_range;
         if (p.min_range > 0.0) keep = keep & (dist >= p.min_range);     // opt-in; the reference never applies it
         if (keep) {
             t_out = tbest;
@@ -441,7 +457,12 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
     if (p.out.t) p.out.t[gid] = t_out;
     if (p.out.t_label) ((uint2*)p.out.t_label)[gid] = make_uint2(__float_as_uint(t_out), label);
     if (p.out.prim) p.out.prim[gid] = prim;
-    if (STATS) { nx = st_nodes; ny = st_tris; nz = st_uni + st_dead / 1024.0f; }   // nz = uniform + dead/1024
+    if (STATS) {
+        if (p.stats) {
+            uint32_t* q = p.stats + gid * kStatsWords;
+            q[0] = st_nodes; q[1] = st_tris; q[2] = st_uni; q[3] = st_dead; q[4] = st_pad;
+        }
+    }
     if (p.out.normal3) { float* q = p.out.normal3 + gid * 3; q[0] = nx; q[1] = ny; q[2] = nz; }
     if (p.out.point3) { float* q = p.out.point3 + gid * 3; q[0] = px; q[1] = py; q[2] = pz; }
     if (p.out.sem) p.out.sem[gid] = (uint16_t)(label & 0xFFFFu);
@@ -567,6 +588,13 @@ __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const lrc_compa
     if (io.out_ins) io.out_ins[dst] = io.ins[src];
     if (io.out_incident_deg) io.out_incident_deg[dst] = io.incident_deg[src];
     if (io.out_index) io.out_index[dst] = (uint32_t)i;
+    if (io.out_range_origin) {
+        // |p| from the WORLD origin in float32 exactly as np.linalg.norm(points, axis=1) forms it: squares, the
+        // 3-element add.reduce left to right, one sqrt -- the quantity the reference's ScanQuality range statistics are
+        // taken over (s3dis_simulator.py:283-284)
+        const float* sp = io.point3 + src * 3;
+        io.out_range_origin[dst] = __builtin_sqrtf((sp[0] * sp[0] + sp[1] * sp[1]) + sp[2] * sp[2]);
+    }
 }
 
 // ---- scene cloud from per-ray (t, label) pairs -------------------------------------------------------
@@ -853,7 +881,7 @@ int lrc_scene_export_bvh(const lrc_scene* s, float* nodes16, uint32_t* slot_prim
     return LRC_OK;
 }
 
-static int launch_trace(lrc_scene* s, TraceParams& p, bool gen, hipStream_t st) {
+static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, bool stats = false) {
     p.nodes = s->d_nodes;
     p.tris = s->d_tris;
     p.slot_prim = s->d_slot_prim;
@@ -883,11 +911,13 @@ static int launch_trace(lrc_scene* s, TraceParams& p, bool gen, hipStream_t st) 
         else if (uni) { if (leafw == 2) LRC_LAUNCH(G, 2, true, false); else LRC_LAUNCH(G, 1, true, false); }  \
         else { if (leafw == 2) LRC_LAUNCH(G, 2, false, false); else LRC_LAUNCH(G, 1, false, false); }         \
     } while (0)
-    static const int stats = [] { const char* e = std::getenv("LRC_STATS"); return e ? std::atoi(e) : 0; }();
-    if (stats) {   // diagnostic build: per-ray traversal counters replace the normals (tools/trav_stats.py)
-        if (gen) hipLaunchKernelGGL((trace_kernel<true, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
-        else hipLaunchKernelGGL((trace_kernel<false, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
-    } else if (gen) LRC_PICK(true); else LRC_PICK(false);
+    if (stats) {   // diagnostic build: per-ray traversal counters (lrc_debug_scan_stats)
+        if (gen == 1) hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
+        else if (gen == 0) hipLaunchKernelGGL((trace_kernel<0, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
+        else return fail(LRC_ERR_INVALID_ARG, "traversal statistics are not available for the scan-angle generator");
+    } else if (gen == 1) LRC_PICK(1);
+    else if (gen == 2) LRC_LAUNCH(2, 1, true, false);
+    else LRC_PICK(0);
 #undef LRC_PICK
 #undef LRC_LAUNCH
     LRC_HIP(hipGetLastError());
@@ -902,9 +932,9 @@ int lrc_scene_get_occupancy(const lrc_scene* s, int* waves_per_cu, int* vgprs, i
     const uint32_t depth = s->info.max_depth < 1 ? 1 : s->info.max_depth;
     const size_t lds = (size_t)depth * kTBlock * sizeof(int);
     int blocks = 0;
-    LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<true, 1, true, false, false>, kTBlock, lds));
+    LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<1, 1, true, false, false>, kTBlock, lds));
     hipFuncAttributes attr;
-    LRC_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trace_kernel<true, 1, true, false, false>)));
+    LRC_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trace_kernel<1, 1, true, false, false>)));
     if (waves_per_cu) *waves_per_cu = blocks * (kTBlock / 64);
     if (vgprs) *vgprs = attr.numRegs;
     if (lds_bytes) *lds_bytes = (int)lds;
@@ -924,7 +954,7 @@ int lrc_cast_dev(lrc_scene* s, const float* d_rays6, uint64_t n, const double* c
     if (center3) { p.cx = center3[0]; p.cy = center3[1]; p.cz = center3[2]; }
     p.max_range = max_range;
     p.out = *d_out;
-    return launch_trace(s, p, false, (hipStream_t)stream);
+    return launch_trace(s, p, 0, (hipStream_t)stream);
 }
 
 int lrc_cast_segments_dev(lrc_scene* s, const float* d_rays6, uint64_t n, const uint64_t* d_seg_offsets,
@@ -945,7 +975,7 @@ int lrc_cast_segments_dev(lrc_scene* s, const float* d_rays6, uint64_t n, const 
     p.has_center = 1;
     p.max_range = max_range;
     p.out = *d_out;
-    return launch_trace(s, p, false, (hipStream_t)stream);
+    return launch_trace(s, p, 0, (hipStream_t)stream);
 }
 
 int lrc_scan_poses_dev(lrc_scene* s, const double* d_poses16, uint64_t P, const double* d_dirs3,
@@ -962,7 +992,7 @@ int lrc_scan_poses_dev(lrc_scene* s, const double* d_poses16, uint64_t P, const 
     p.has_center = 1;
     p.max_range = max_range;
     p.out = *d_out;
-    return launch_trace(s, p, true, (hipStream_t)stream);
+    return launch_trace(s, p, 1, (hipStream_t)stream);
 }
 
 // ---- host-pointer convenience wrappers ---------------------------------------------------------
@@ -1115,7 +1145,7 @@ int lrc_compact_dev(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_com
     if (!ctx || !io) return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: NULL argument");
     if (nseg == 0 || seg_len == 0) return LRC_OK;
     if (!io->t) return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: t is NULL");
-    if (((io->out_point3 || io->out_xyzl) && !io->point3) || (io->out_sem && !io->sem) ||
+    if (((io->out_point3 || io->out_xyzl || io->out_range_origin) && !io->point3) || (io->out_sem && !io->sem) ||
         (io->out_ins && !io->ins) || (io->out_incident_deg && !io->incident_deg))
         return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: an output is requested without its input");
     LRC_HIP(hipSetDevice(ctx->device));
@@ -1324,6 +1354,197 @@ int lrc_compact(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_compact
         if (io->out_index) LRC_HIP(hipMemcpy(io->out_index, d.out_index, K * 4, hipMemcpyDeviceToHost));
         if (io->out_xyzl) LRC_HIP(hipMemcpy(io->out_xyzl, d.out_xyzl, K * 16, hipMemcpyDeviceToHost));
     }
+    return LRC_OK;
+}
+
+
+// ---- scan straight to the reference's variable-length frames ----------------------------------------------------
+namespace {
+// compacted frame arrays in HBM (context pool) and the record set they are compacted from
+struct FrameStage {
+    DevBuf t, p3, sem, ins, inc, tile;                     // fixed-stride records
+    DevBuf cnt, op3, osem, oins, oinc, oidx, oxyzl, orng;   // compacted outputs
+    lrc_hits rec{};
+    lrc_compact_io io{};
+    int alloc(lrc_ctx* ctx, const lrc_frames& f, uint64_t P, uint64_t n) {
+        int rc;
+        const bool want_pt = f.point3 || f.xyzl || f.range_origin;
+        const bool want_sem = f.sem || f.xyzl, want_ins = f.ins || f.xyzl;
+        if ((rc = t.get(ctx, kPoolT, n * 4))) return rc;
+        rec.t = (float*)t.p;
+        if (want_pt) { if ((rc = p3.get(ctx, kPoolPoint, n * 12))) return rc; rec.point3 = (float*)p3.p; }
+        if (want_sem) { if ((rc = sem.get(ctx, kPoolSem, n * 2))) return rc; rec.sem = (uint16_t*)sem.p; }
+        if (want_ins) { if ((rc = ins.get(ctx, kPoolIns, n * 2))) return rc; rec.ins = (uint16_t*)ins.p; }
+        if (f.incident_deg) { if ((rc = inc.get(ctx, kPoolInc, n * 8))) return rc; rec.incident_deg = (double*)inc.p; }
+        if ((rc = tile.get(ctx, kPoolTile, ((n + 63) / 64 + 1) * 4))) return rc;
+        rec.tile_count = (uint32_t*)tile.p;
+        io.t = rec.t; io.point3 = rec.point3; io.sem = rec.sem; io.ins = rec.ins; io.incident_deg = rec.incident_deg;
+        io.tile_count = rec.tile_count;
+        if ((rc = cnt.get(ctx, kPoolCounts, P * 8))) return rc;
+        io.counts = (uint64_t*)cnt.p;
+        if (f.point3) { if ((rc = op3.get(ctx, kPoolOutPoint, n * 12))) return rc; io.out_point3 = (float*)op3.p; }
+        if (f.sem) { if ((rc = osem.get(ctx, kPoolOutSem, n * 2))) return rc; io.out_sem = (uint16_t*)osem.p; }
+        if (f.ins) { if ((rc = oins.get(ctx, kPoolOutIns, n * 2))) return rc; io.out_ins = (uint16_t*)oins.p; }
+        if (f.incident_deg) { if ((rc = oinc.get(ctx, kPoolOutInc, n * 8))) return rc; io.out_incident_deg = (double*)oinc.p; }
+        if (f.index) { if ((rc = oidx.get(ctx, kPoolOutIdx, n * 4))) return rc; io.out_index = (uint32_t*)oidx.p; }
+        if (f.xyzl) { if ((rc = oxyzl.get(ctx, kPoolOutXyzl, n * 16))) return rc; io.out_xyzl = (float*)oxyzl.p; }
+        if (f.range_origin) { if ((rc = orng.get(ctx, kPoolOutRange, n * 4))) return rc; io.out_range_origin = (float*)orng.p; }
+        return LRC_OK;
+    }
+};
+
+// trace (already described by p, outputs wired to st.rec) -> compaction -> counts to the host -> ONE bulk transfer per
+// requested array of exactly the kept rows.  Pinned destinations (lrc_host_alloc) make the transfers true DMA.
+int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_t P, uint64_t N, const lrc_frames* out,
+                  uint64_t capacity, uint64_t* out_total) {
+    p.out = st.rec;
+    int rc = launch_trace(s, p, gen, nullptr);
+    if (rc) return rc;
+    if ((rc = lrc_compact_dev(s->ctx, P, N, &st.io, nullptr))) return rc;
+    LRC_HIP(hipMemcpyAsync(out->counts, st.io.counts, P * 8, hipMemcpyDeviceToHost, nullptr));
+    LRC_HIP(hipStreamSynchronize(nullptr));
+    uint64_t K = 0;
+    for (uint64_t k = 0; k < P; ++k) K += out->counts[k];
+    if (out_total) *out_total = K;
+    if (K > capacity)
+        return fail(LRC_ERR_INVALID_ARG, "frame buffers too small: capacity " + std::to_string(capacity) + " rows, the scan kept " +
+                                             std::to_string(K));
+    if (!K) return LRC_OK;
+    if (out->point3) LRC_HIP(hipMemcpyAsync(out->point3, st.io.out_point3, K * 12, hipMemcpyDeviceToHost, nullptr));
+    if (out->sem) LRC_HIP(hipMemcpyAsync(out->sem, st.io.out_sem, K * 2, hipMemcpyDeviceToHost, nullptr));
+    if (out->ins) LRC_HIP(hipMemcpyAsync(out->ins, st.io.out_ins, K * 2, hipMemcpyDeviceToHost, nullptr));
+    if (out->incident_deg)
+        LRC_HIP(hipMemcpyAsync(out->incident_deg, st.io.out_incident_deg, K * 8, hipMemcpyDeviceToHost, nullptr));
+    if (out->index) LRC_HIP(hipMemcpyAsync(out->index, st.io.out_index, K * 4, hipMemcpyDeviceToHost, nullptr));
+    if (out->xyzl) LRC_HIP(hipMemcpyAsync(out->xyzl, st.io.out_xyzl, K * 16, hipMemcpyDeviceToHost, nullptr));
+    if (out->range_origin)
+        LRC_HIP(hipMemcpyAsync(out->range_origin, st.io.out_range_origin, K * 4, hipMemcpyDeviceToHost, nullptr));
+    LRC_HIP(hipStreamSynchronize(nullptr));
+    return LRC_OK;
+}
+}  // namespace
+
+int lrc_host_alloc(lrc_ctx* ctx, uint64_t bytes, void** out_ptr) {
+    if (!ctx || !out_ptr) return fail(LRC_ERR_INVALID_ARG, "lrc_host_alloc: NULL argument");
+    *out_ptr = nullptr;
+    if (!bytes) return LRC_OK;
+    LRC_HIP(hipSetDevice(ctx->device));
+    LRC_HIP(hipHostMalloc(out_ptr, bytes, hipHostMallocDefault));
+    return LRC_OK;
+}
+
+int lrc_host_free(lrc_ctx* ctx, void* ptr) {
+    if (!ptr) return LRC_OK;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    LRC_HIP(hipHostFree(ptr));
+    return LRC_OK;
+}
+
+int lrc_scan_poses_compact(lrc_scene* s, const double* poses16, uint64_t P, const double* dirs3, uint64_t N,
+                           double max_range, const lrc_frames* out, uint64_t capacity, uint64_t* out_total) {
+    if (out_total) *out_total = 0;
+    if (!s || !out) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_poses_compact: NULL scene or output");
+    const uint64_t n = P * N;
+    if (!n) return LRC_OK;
+    if (!poses16 || !dirs3 || !out->counts)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_scan_poses_compact: poses16, dirs3 or counts is NULL");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    DevBuf dp, dd;
+    int rc;
+    if ((rc = dp.get(s->ctx, kPoolPoses, P * 128)) || (rc = dd.get(s->ctx, kPoolDirs, N * 24))) return rc;
+    LRC_HIP(hipMemcpyAsync(dp.p, poses16, P * 128, hipMemcpyHostToDevice, nullptr));
+    LRC_HIP(hipMemcpyAsync(dd.p, dirs3, N * 24, hipMemcpyHostToDevice, nullptr));
+    FrameStage st;
+    if ((rc = st.alloc(s->ctx, *out, P, n))) return rc;
+    NoiseStage ns;
+    if ((rc = ns.begin(s, n))) return rc;
+    TraceParams p{};
+    p.poses16 = (const double*)dp.p;
+    p.dirs3 = (const double*)dd.p;
+    p.rays_per_pose = N;
+    p.total = n;
+    p.has_center = 1;
+    p.max_range = max_range;
+    return frames_finish(s, p, 1, st, P, N, out, capacity, out_total);
+}
+
+int lrc_scan_angles_dev(lrc_scene* s, const double* d_poses16, uint64_t P, const double* d_angles2,
+                        const uint8_t* d_keep, uint64_t N, double max_range, const lrc_hits* d_out, void* stream) {
+    if (!s || !d_out) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_angles_dev: NULL scene or output");
+    if (P && N && (!d_poses16 || !d_angles2))
+        return fail(LRC_ERR_INVALID_ARG, "lrc_scan_angles_dev: poses16 or angles2 is NULL");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    TraceParams p{};
+    p.poses16 = d_poses16;
+    p.angles2 = d_angles2;
+    p.keep_mask = d_keep;
+    p.rays_per_pose = N ? N : 1;
+    p.total = P * N;
+    p.has_center = 1;
+    p.max_range = max_range;
+    p.out = *d_out;
+    return launch_trace(s, p, 2, (hipStream_t)stream);
+}
+
+int lrc_scan_angles_compact(lrc_scene* s, const double* poses16, uint64_t P, const double* angles2,
+                            const uint8_t* keep, uint64_t N, double max_range, const lrc_frames* out,
+                            uint64_t capacity, uint64_t* out_total) {
+    if (out_total) *out_total = 0;
+    if (!s || !out) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_angles_compact: NULL scene or output");
+    const uint64_t n = P * N;
+    if (!n) return LRC_OK;
+    if (!poses16 || !angles2 || !out->counts)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_scan_angles_compact: poses16, angles2 or counts is NULL");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    DevBuf dp, da, dk;
+    int rc;
+    if ((rc = dp.get(s->ctx, kPoolPoses, P * 128)) || (rc = da.get(s->ctx, kPoolAngles, n * 16))) return rc;
+    LRC_HIP(hipMemcpyAsync(dp.p, poses16, P * 128, hipMemcpyHostToDevice, nullptr));
+    LRC_HIP(hipMemcpyAsync(da.p, angles2, n * 16, hipMemcpyHostToDevice, nullptr));
+    if (keep) {
+        if ((rc = dk.get(s->ctx, kPoolKeep, n))) return rc;
+        LRC_HIP(hipMemcpyAsync(dk.p, keep, n, hipMemcpyHostToDevice, nullptr));
+    }
+    FrameStage st;
+    if ((rc = st.alloc(s->ctx, *out, P, n))) return rc;
+    NoiseStage ns;
+    if ((rc = ns.begin(s, n))) return rc;
+    TraceParams p{};
+    p.poses16 = (const double*)dp.p;
+    p.angles2 = (const double*)da.p;
+    p.keep_mask = keep ? (const uint8_t*)dk.p : nullptr;
+    p.rays_per_pose = N;
+    p.total = n;
+    p.has_center = 1;
+    p.max_range = max_range;
+    return frames_finish(s, p, 2, st, P, N, out, capacity, out_total);
+}
+
+int lrc_debug_scan_stats(lrc_scene* s, const double* poses16, uint64_t P, const double* dirs3, uint64_t N,
+                         double max_range, uint32_t* stats) {
+    if (!s || !stats) return fail(LRC_ERR_INVALID_ARG, "lrc_debug_scan_stats: NULL scene or output");
+    const uint64_t n = P * N;
+    if (!n) return LRC_OK;
+    if (!poses16 || !dirs3) return fail(LRC_ERR_INVALID_ARG, "lrc_debug_scan_stats: poses16 or dirs3 is NULL");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    DevBuf dp, dd, ds;
+    int rc;
+    if ((rc = dp.get(s->ctx, kPoolPoses, P * 128)) || (rc = dd.get(s->ctx, kPoolDirs, N * 24)) ||
+        (rc = ds.get(s->ctx, kPoolStats, n * kStatsWords * 4)))
+        return rc;
+    LRC_HIP(hipMemcpy(dp.p, poses16, P * 128, hipMemcpyHostToDevice));
+    LRC_HIP(hipMemcpy(dd.p, dirs3, N * 24, hipMemcpyHostToDevice));
+    TraceParams p{};
+    p.poses16 = (const double*)dp.p;
+    p.dirs3 = (const double*)dd.p;
+    p.rays_per_pose = N;
+    p.total = n;
+    p.has_center = 1;
+    p.max_range = max_range;
+    p.stats = (uint32_t*)ds.p;
+    if ((rc = launch_trace(s, p, 1, nullptr, true))) return rc;
+    LRC_HIP(hipDeviceSynchronize());
+    LRC_HIP(hipMemcpy(stats, ds.p, n * kStatsWords * 4, hipMemcpyDeviceToHost));
     return LRC_OK;
 }
 

@@ -75,7 +75,10 @@ LRC_DI void slab_interval(const RaySlab& s, float lox, float loy, float loz, flo
 //   den = Ng.D != 0,  U = (C x D).e2,  V = (C x D).e1 (sign-corrected), U,V >= 0, U+V <= |den|,
 //   T = Ng.C (sign-corrected) > 0,  t = T/|den| finite and inside the padded slab interval of the
 //   triangle's own bounding box.
-LRC_DI bool tri_hit(V3 o, V3 d, const RaySlab& s, V3 v0, V3 v1, V3 v2, V3 ng, float& t_out) {
+// DIAG builds (lrc_debug_scan_stats) count in pad_rej the triangles that pass every Moeller-Trumbore condition and are
+// rejected by the box clause alone -- the one clause Embree does not have; the product build compiles the counter away.
+template <bool DIAG = false>
+LRC_DI bool tri_hit(V3 o, V3 d, const RaySlab& s, V3 v0, V3 v1, V3 v2, V3 ng, float& t_out, uint32_t* pad_rej = nullptr) {
     V3 e1 = sub3(v0, v1);
     V3 e2 = sub3(v2, v0);
     V3 c = sub3(v0, o);
@@ -94,9 +97,21 @@ LRC_DI bool tri_hit(V3 o, V3 d, const RaySlab& s, V3 v0, V3 v1, V3 v2, V3 ng, fl
     float loz = min2(min2(v0.z, v1.z), v2.z), hiz = max2(max2(v0.z, v1.z), v2.z);
     float tn, tf;
     slab_interval(s, lox, loy, loz, hix, hiy, hiz, tn, tf);
-    if (!((tn <= t) & (t <= tf) & (t < __builtin_inff()))) return false;
+    if (!((tn <= t) & (t <= tf) & (t < __builtin_inff()))) {
+        if (DIAG) { if (t < __builtin_inff()) *pad_rej += 1u; }
+        return false;
+    }
     t_out = t;
     return true;
+}
+
+// A ray takes part in the cast only if its six components are finite (bit test: immune to -fno-honor-nans).  Anything
+// else is reported as a miss without touching the tree, so no comparison ever sees a NaN (include/lidarcast.h,
+// "finite-ray contract"; the oracle applies the same rule).
+LRC_DI bool finite_ray(V3 o, V3 d) {
+    const uint32_t m = 0x7F800000u;
+    return ((__float_as_uint(o.x) & m) != m) & ((__float_as_uint(o.y) & m) != m) & ((__float_as_uint(o.z) & m) != m) &
+           ((__float_as_uint(d.x) & m) != m) & ((__float_as_uint(d.y) & m) != m) & ((__float_as_uint(d.z) & m) != m);
 }
 
 // One output of np.dot(directions, R.T): the BLAS kernel accumulates over k from a +0.0 accumulator with fused
@@ -120,6 +135,22 @@ LRC_DI void gen_ray(const double* poses16, const double* dirs3, uint64_t pose, u
     d.x = (float)dgemm_row(a, b, c, M[0], M[1], M[2]);
     d.y = (float)dgemm_row(a, b, c, M[4], M[5], M[6]);
     d.z = (float)dgemm_row(a, b, c, M[8], M[9], M[10]);
+    cx = M[3]; cy = M[7]; cz = M[11];
+    o.x = (float)cx; o.y = (float)cy; o.z = (float)cz;
+}
+
+// Ray (pose, i) of the dual-axis sensor from its noisy scan angles (phi, theta), float64, drawn on the host from the
+// seeded stream (lidar/indoor_lidar.py:270-272): d = (cos(theta)cos(phi), cos(theta)sin(phi), sin(theta)), rotated as
+// the reference rotates it, ray by ray with numpy's un-fused (d0*R[:,0] + d1*R[:,1]) + d2*R[:,2] (:283-287), then
+// narrowed to float32.  Opt-in path: the device's double sin/cos are not guaranteed to round like the host's libm.
+LRC_DI void gen_ray_angles(const double* poses16, uint64_t pose, double phi, double theta, V3& o, V3& d,
+                           double& cx, double& cy, double& cz) {
+    const double* M = poses16 + pose * 16;
+    const double ct = cos(theta);
+    const double d0 = ct * cos(phi), d1 = ct * sin(phi), d2 = sin(theta);
+    d.x = (float)((d0 * M[0] + d1 * M[1]) + d2 * M[2]);
+    d.y = (float)((d0 * M[4] + d1 * M[5]) + d2 * M[6]);
+    d.z = (float)((d0 * M[8] + d1 * M[9]) + d2 * M[10]);
     cx = M[3]; cy = M[7]; cz = M[11];
     o.x = (float)cx; o.y = (float)cy; o.z = (float)cz;
 }

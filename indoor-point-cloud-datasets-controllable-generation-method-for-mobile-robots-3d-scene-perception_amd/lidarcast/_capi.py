@@ -26,7 +26,8 @@ SYMBOLS = (
     "lrc_scene_create", "lrc_scene_destroy", "lrc_scene_get_info", "lrc_scene_export_bvh",
     "lrc_scene_get_counters", "lrc_scene_set_options", "lrc_scene_get_occupancy",
     "lrc_cast", "lrc_cast_dev", "lrc_cast_segments", "lrc_cast_segments_dev",
-    "lrc_scan_poses", "lrc_scan_poses_dev",
+    "lrc_scan_poses", "lrc_scan_poses_dev", "lrc_scan_poses_compact", "lrc_host_alloc", "lrc_host_free",
+    "lrc_scan_angles_dev", "lrc_scan_angles_compact", "lrc_debug_scan_stats",
     "lrc_compact", "lrc_compact_dev", "lrc_cloud_from_ranges_dev", "lrc_cloud_from_prims_dev",
     "lrc_nn_create", "lrc_nn_destroy", "lrc_nn_query", "lrc_nn_query_dev",
     "lrc_min_distances", "lrc_rbf_kernel_sum",
@@ -58,7 +59,17 @@ class LrcCompactIO(C.Structure):
     _fields_ = [("t", C.c_void_p), ("point3", C.c_void_p), ("sem", C.c_void_p), ("ins", C.c_void_p),
                 ("incident_deg", C.c_void_p), ("tile_count", C.c_void_p), ("counts", C.c_void_p),
                 ("out_point3", C.c_void_p), ("out_sem", C.c_void_p), ("out_ins", C.c_void_p),
-                ("out_incident_deg", C.c_void_p), ("out_index", C.c_void_p), ("out_xyzl", C.c_void_p)]
+                ("out_incident_deg", C.c_void_p), ("out_index", C.c_void_p), ("out_xyzl", C.c_void_p),
+                ("out_range_origin", C.c_void_p)]
+
+
+class LrcFrames(C.Structure):
+    _fields_ = [("counts", C.c_void_p), ("point3", C.c_void_p), ("sem", C.c_void_p), ("ins", C.c_void_p),
+                ("incident_deg", C.c_void_p), ("index", C.c_void_p), ("xyzl", C.c_void_p),
+                ("range_origin", C.c_void_p)]
+
+
+LRC_STATS_WORDS = 5
 
 
 _lib = None
@@ -99,6 +110,12 @@ def load():
         "lrc_cast_segments_dev": [vp, vp, u64, vp, u64, vp, dbl, C.POINTER(LrcHits), vp],
         "lrc_scan_poses": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcHits)],
         "lrc_scan_poses_dev": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcHits), vp],
+        "lrc_scan_poses_compact": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcFrames), u64, C.POINTER(u64)],
+        "lrc_host_alloc": [vp, u64, C.POINTER(vp)],
+        "lrc_host_free": [vp, vp],
+        "lrc_scan_angles_dev": [vp, vp, u64, vp, vp, u64, dbl, C.POINTER(LrcHits), vp],
+        "lrc_scan_angles_compact": [vp, vp, u64, vp, vp, u64, dbl, C.POINTER(LrcFrames), u64, C.POINTER(u64)],
+        "lrc_debug_scan_stats": [vp, vp, u64, vp, u64, dbl, vp],
         "lrc_occ_create": [vp, vp, u64, C.POINTER(vp)],
         "lrc_occ_destroy": [vp],
         "lrc_occ_query": [vp, vp, u64, dbl, vp],

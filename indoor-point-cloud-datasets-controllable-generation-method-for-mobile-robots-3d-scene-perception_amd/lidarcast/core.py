@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import LrcCompactIO, LrcHits, LrcScanOptions, LrcSceneInfo, check
+from ._capi import LRC_STATS_WORDS, LrcCompactIO, LrcFrames, LrcHits, LrcScanOptions, LrcSceneInfo, check
 
 ATTRS = ("t", "prim", "normal3", "point3", "sem", "ins", "incident_deg")
 _NP_SPEC = {
@@ -26,6 +26,77 @@ def _ptr(a):
     return None if a is None else C.c_void_p(a.ctypes.data)
 
 
+FRAME_ATTRS = ("point3", "sem", "ins", "incident_deg", "index", "xyzl", "range_origin")
+_FRAME_SPEC = {"point3": (np.float32, (3,)), "sem": (np.uint16, ()), "ins": (np.uint16, ()),
+               "incident_deg": (np.float64, ()), "index": (np.uint32, ()), "xyzl": (np.float32, (4,)),
+               "range_origin": (np.float32, ())}
+
+
+class _PinnedBlock:
+    """One page-locked host allocation (lrc_host_alloc).  numpy arrays handed out are views of ``buf``; when the
+    last view dies the block goes back to its pool (or is freed when the pool is gone or full)."""
+
+    def __init__(self, pool, ptr, nbytes):
+        self.pool, self.ptr, self.nbytes = pool, ptr, nbytes
+
+
+class PinnedPool:
+    """Page-locked host buffers for the frame arrays of the *_compact entry points, recycled by size class.
+
+    ``take(nbytes)`` returns a uint8 numpy array over pinned memory.  Arrays sliced / viewed from it keep the
+    allocation alive; once the caller drops every view the block returns to the pool, so a simulator that scans
+    trajectory after trajectory re-uses the same pinned pages instead of paying hipHostMalloc (milliseconds per
+    100 MB) each time, and frames a caller still holds are never overwritten.
+    """
+
+    def __init__(self, ctx, max_free_bytes=1 << 30):
+        self._ctx = ctx
+        self._free = {}            # size class -> [ptr, ...]
+        self._free_bytes = 0
+        self._max_free = int(max_free_bytes)
+        self.allocations = 0       # hipHostMalloc calls so far (tests / bench bookkeeping)
+
+    @staticmethod
+    def _klass(nbytes):
+        k = 1 << 16
+        while k < nbytes:
+            k <<= 1
+        return k
+
+    def take(self, nbytes):
+        import weakref
+        k = self._klass(max(int(nbytes), 1))
+        lst = self._free.get(k)
+        if lst:
+            ptr = lst.pop()
+            self._free_bytes -= k
+        else:
+            p = C.c_void_p()
+            check(self._ctx._lib.lrc_host_alloc(self._ctx._h, k, C.byref(p)), "lrc_host_alloc")
+            ptr = p.value
+            self.allocations += 1
+        raw = (C.c_uint8 * k).from_address(ptr)
+        weakref.finalize(raw, PinnedPool._release, weakref.ref(self), ptr, k, self._ctx)
+        return np.frombuffer(raw, dtype=np.uint8, count=k)
+
+    @staticmethod
+    def _release(pool_ref, ptr, k, ctx):
+        pool = pool_ref()
+        if pool is not None and pool._free_bytes + k <= pool._max_free and getattr(ctx, "_h", None):
+            pool._free.setdefault(k, []).append(ptr)
+            pool._free_bytes += k
+        elif getattr(ctx, "_h", None):
+            ctx._lib.lrc_host_free(ctx._h, C.c_void_p(ptr))
+
+    def clear(self):
+        for lst in self._free.values():
+            for ptr in lst:
+                if getattr(self._ctx, "_h", None):
+                    self._ctx._lib.lrc_host_free(self._ctx._h, C.c_void_p(ptr))
+        self._free.clear()
+        self._free_bytes = 0
+
+
 class Context:
     """One HIP device.  Raises (LidarcastError) when there is no GPU or the library is missing."""
 
@@ -35,12 +106,14 @@ class Context:
         check(self._lib.lrc_ctx_create(int(device), C.byref(h)), "lrc_ctx_create")
         self._h = h
         self.device = int(device)
+        self.pinned = PinnedPool(self)
 
     def synchronize(self):
         check(self._lib.lrc_ctx_synchronize(self._h), "lrc_ctx_synchronize")
 
     def close(self):
         if getattr(self, "_h", None):
+            self.pinned.clear()
             self._lib.lrc_ctx_destroy(self._h)
             self._h = None
 
@@ -276,7 +349,85 @@ class Scene:
                                        C.byref(st)), "lrc_scan_poses")
         return outs
 
+    # ---- straight to frames ---------------------------------------------------------------------
+    def _frames_begin(self, P, n, want, capacity):
+        cap = int(n if capacity is None else capacity)
+        fr = LrcFrames()
+        counts = np.zeros(P, dtype=np.uint64)
+        fr.counts = counts.ctypes.data
+        bufs = {}
+        for a in want:
+            if a not in _FRAME_SPEC:
+                raise ValueError(f"unknown frame attribute {a!r}")
+            dt, tail = _FRAME_SPEC[a]
+            width = int(np.prod(tail, dtype=np.int64)) if tail else 1
+            raw = self.ctx.pinned.take(max(cap, 1) * width * np.dtype(dt).itemsize)
+            bufs[a] = raw[:cap * width * np.dtype(dt).itemsize].view(dt).reshape((cap,) + tail)
+            setattr(fr, a, bufs[a].ctypes.data)
+        return fr, counts, bufs, cap
+
+    @staticmethod
+    def _frames_end(counts, bufs, total):
+        out = {a: b[:total] for a, b in bufs.items()}
+        out["counts"] = counts.astype(np.int64)
+        out["total"] = int(total)
+        return out
+
+    def scan_poses_compact(self, poses, dirs, max_range, want=("point3", "sem", "ins"), capacity=None):
+        """Pose-batched scan straight to the kept rows of every pose (lrc_scan_poses_compact): dict of (K, ...)
+        arrays over page-locked memory + ``counts`` (P,) int64 + ``total`` K.  Frame p = rows
+        [counts[:p].sum(), counts[:p+1].sum())."""
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 16)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float64)
+        if dirs.ndim != 2 or dirs.shape[1] != 3:
+            raise ValueError("dirs must be (N, 3)")
+        P, N = poses.shape[0], dirs.shape[0]
+        fr, counts, bufs, cap = self._frames_begin(P, P * N, want, capacity)
+        total = C.c_uint64(0)
+        check(self._lib.lrc_scan_poses_compact(self._h, _ptr(poses), P, _ptr(dirs), N, float(max_range),
+                                               C.byref(fr), cap, C.byref(total)), "lrc_scan_poses_compact")
+        return self._frames_end(counts, bufs, total.value)
+
+    def scan_angles_compact(self, poses, angles, keep, max_range, want=("point3", "sem", "ins"), capacity=None):
+        """Dual-axis sensor, rays generated in the kernel from host-drawn (phi, theta) (lrc_scan_angles_compact).
+        angles: (P, N, 2) float64; keep: (P, N) bool / uint8 or None."""
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 16)
+        angles = np.ascontiguousarray(angles, dtype=np.float64)
+        P = poses.shape[0]
+        if angles.ndim != 3 or angles.shape[0] != P or angles.shape[2] != 2:
+            raise ValueError("angles must be (P, N, 2)")
+        N = angles.shape[1]
+        k8 = None
+        if keep is not None:
+            k8 = np.ascontiguousarray(keep).reshape(P, N).view(np.uint8) if np.asarray(keep).dtype == np.bool_ \
+                else np.ascontiguousarray(keep, dtype=np.uint8).reshape(P, N)
+        fr, counts, bufs, cap = self._frames_begin(P, P * N, want, capacity)
+        total = C.c_uint64(0)
+        check(self._lib.lrc_scan_angles_compact(self._h, _ptr(poses), P, _ptr(angles), _ptr(k8), N, float(max_range),
+                                                C.byref(fr), cap, C.byref(total)), "lrc_scan_angles_compact")
+        return self._frames_end(counts, bufs, total.value)
+
+    def scan_stats(self, poses, dirs, max_range):
+        """(P*N, 5) uint32 traversal counters per ray from the instrumented trace kernel (lrc_debug_scan_stats):
+        node steps, triangle tests, wave-uniform node steps, dead node steps, pad-clause rejections."""
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 16)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float64)
+        P, N = poses.shape[0], dirs.shape[0]
+        st = np.zeros((P * N, LRC_STATS_WORDS), dtype=np.uint32)
+        check(self._lib.lrc_debug_scan_stats(self._h, _ptr(poses), P, _ptr(dirs), N, float(max_range), _ptr(st)),
+              "lrc_debug_scan_stats")
+        return st
+
     # ---- device tensors -------------------------------------------------------------------------
+    def scan_angles_dev(self, poses_t, angles_t, keep_t, hits, max_range, stream=0):
+        P = poses_t.shape[0]
+        N = angles_t.shape[0] // max(P, 1) if angles_t.dim() == 2 else angles_t.shape[1]
+        check(self._lib.lrc_scan_angles_dev(self._h, C.c_void_p(poses_t.data_ptr()), P,
+                                            C.c_void_p(angles_t.data_ptr()),
+                                            None if keep_t is None else C.c_void_p(keep_t.data_ptr()), N,
+                                            float(max_range), C.byref(hits.struct), C.c_void_p(int(stream))),
+              "lrc_scan_angles_dev")
+
     def cast_dev(self, rays_t, hits, center=None, max_range=np.inf, stream=0):
         c = None if center is None else np.ascontiguousarray(center, dtype=np.float64).reshape(3)
         check(self._lib.lrc_cast_dev(self._h, C.c_void_p(rays_t.data_ptr()), rays_t.shape[0], _ptr(c),

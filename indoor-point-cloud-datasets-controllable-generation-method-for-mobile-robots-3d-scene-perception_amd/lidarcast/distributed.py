@@ -30,9 +30,9 @@ class CloudGather:
     collective.  Every rank contributes the same fixed size because RCCL has no all-gather-v.
     """
 
-    def __init__(self, max_local, max_poses, dist, device):
+    def __init__(self, max_local, max_poses, dist, device, group=None):
         import torch
-        self.dist, self.world = dist, dist.get_world_size()
+        self.dist, self.group, self.world = dist, group, dist.get_world_size(group)
         self.max_local, self.max_poses = int(max_local), int(max_poses)
         self.tail = (self.max_poses * 8 + 15) // 16
         self.rows = self.max_local + self.tail
@@ -43,7 +43,7 @@ class CloudGather:
 
     def gather(self, async_op=False):
         """Enqueue the all-gather.  async_op=True returns at once; ``wait()`` before touching the buffers."""
-        self.work = self.dist.all_gather_into_tensor(self.all_rows, self.slab, async_op=async_op)
+        self.work = self.dist.all_gather_into_tensor(self.all_rows, self.slab, group=self.group, async_op=async_op)
 
     def wait(self):
         if self.work is not None:
@@ -106,10 +106,10 @@ class PrimGather:
     global pose order (ranks own contiguous pose blocks of ``poses_local`` poses; a rank with fewer poses pads with
     -1 ids).  One collective per scan, half the bytes of RangeGather on the xGMI links."""
 
-    def __init__(self, poses_local, rays_per_pose, dist, device, world=None):
+    def __init__(self, poses_local, rays_per_pose, dist, device, world=None, group=None):
         import torch
-        self.dist = dist
-        self.world = dist.get_world_size() if world is None else int(world)
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group) if world is None else int(world)
         self.poses_local, self.rays_per_pose = int(poses_local), int(rays_per_pose)
         self.n = self.poses_local * self.rays_per_pose
         self.fused_counts = self.rays_per_pose % 64 == 0
@@ -123,7 +123,7 @@ class PrimGather:
             self.tile_count.zero_()
         self.all_slabs = torch.empty((self.world * self.words,), dtype=torch.int32, device=device)
         # ``world`` may exceed the process group (single-GPU diagnostics): the collective fills the leading slabs
-        self.recv = self.all_slabs[:dist.get_world_size() * self.words]
+        self.recv = self.all_slabs[:dist.get_world_size(group) * self.words]
         self.work = None
 
     @property
@@ -136,7 +136,7 @@ class PrimGather:
         return self.all_slabs[self.n:] if self.fused_counts else None
 
     def gather(self, async_op=False):
-        self.work = self.dist.all_gather_into_tensor(self.recv, self.slab, async_op=async_op)
+        self.work = self.dist.all_gather_into_tensor(self.recv, self.slab, group=self.group, async_op=async_op)
 
     def wait(self):
         if self.work is not None:
@@ -167,3 +167,100 @@ def gather_cloud(local_points, local_labels, local_counts, max_local, dist, devi
     g.counts[:local_counts.numel()] = local_counts.to(torch.int64)
     g.gather()
     return g.assemble(nposes.cpu())
+
+
+# ---- the plugin surface on N ranks -------------------------------------------------------------------------------
+def active_group(process_group=None):
+    """(dist module, group) when this process is a rank of an initialised torch.distributed job with more than one
+    rank (or ``process_group`` is given), else (None, None).  torch is not imported for single-process callers."""
+    import sys
+    if process_group is None and "torch" not in sys.modules:
+        return None, None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None, None
+    if dist.get_world_size(process_group) <= 1:
+        return None, None
+    return dist, process_group
+
+
+def scan_frames_sharded(engine, intrinsics, poses, mesh, dist, group=None):
+    """``RaycastEngineGPU.scan_frames`` for a trajectory sharded over the ranks of a process group: contiguous pose
+    blocks (shard_bounds), every rank scans its block against its scene replica, ONE all-gather of the hit triangle
+    ids (PrimGather, 4 B per ray) and every rank rebuilds the whole scene cloud, so every rank returns the frames of
+    ALL poses -- the same bytes as a single-process scan, whatever the number of ranks
+    (reference loop: s3dis_simulator.py:254-288; assembly order: containers/s3dis_sim_scene.py:326).
+
+    The engine supplies three device steps (RaycastEngineHIP implements them with the HIP kernels; the CPU tests
+    plug in a stand-in so that sharding, gather and ordering run under gloo without a GPU):
+      engine.prim_gather(poses_local, rays_per_pose, dist, group) -> PrimGather
+      engine.scan_block_into(gather, intrinsics, block_poses, mesh)       trace -> ids + keep counts in the send slab
+      engine.cloud_from_gather(gather, intrinsics, padded_poses, mesh)    -> (rows (K,4) f32 numpy, counts numpy)
+    """
+    poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 4, 4)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    P = len(poses)
+    b = shard_bounds(P, world)
+    per = int(max(b[1:] - b[:-1])) if P else 0
+    if per == 0:
+        return {"point3": np.zeros((0, 3), np.float32), "sem": np.zeros(0, np.uint16), "ins": np.zeros(0, np.uint16),
+                "counts": np.zeros(0, np.int64), "total": 0}
+    n_rays = len(engine._direction_table(intrinsics))
+    g = engine.prim_gather(per, n_rays, dist, group)
+    engine.scan_block_into(g, intrinsics, poses[b[rank]:b[rank + 1]], mesh)
+    g.gather()                                   # the ONE collective of the scan
+    padded = np.tile(np.eye(4), (world * per, 1, 1))
+    for r in range(world):
+        padded[r * per:r * per + (b[r + 1] - b[r])] = poses[b[r]:b[r + 1]]
+    rows, counts = engine.cloud_from_gather(g, intrinsics, padded, mesh)
+    real = np.concatenate([np.arange(r * per, r * per + (b[r + 1] - b[r])) for r in range(world)]).astype(np.int64)
+    counts = np.asarray(counts, dtype=np.int64)
+    assert int(counts.sum()) == int(counts[real].sum()), "a padded pose produced returns"
+    lab = np.ascontiguousarray(rows[:, 3]).view(np.uint32)
+    return {"point3": np.ascontiguousarray(rows[:, :3]), "sem": (lab & 0xFFFF).astype(np.uint16),
+            "ins": (lab >> 16).astype(np.uint16), "counts": counts[real], "total": int(len(rows))}
+
+
+def scan_lidars_sharded(engine, lidars, mesh, dist, group=None, device=None):
+    """Host-generated rays (dual-axis sensor) on N ranks.  Every rank draws the rays of EVERY pose, in pose order, from
+    the one numpy stream -- so the rays do not depend on N and the stream ends where a single process would leave it
+    -- casts its contiguous block of poses in one launch, compacts it, and joins ONE all-gather of the 16-byte rows
+    (CloudGather).  Returns the frames of all poses (same dict as scan_frames_sharded, plus incident_deg=None)."""
+    import torch
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    P = len(lidars)
+    b = shard_bounds(P, world)
+    rays = [l.get_rays() for l in lidars]              # the whole trajectory's stream, on every rank
+
+    class _Drawn:                                       # a sensor whose rays were already drawn
+        def __init__(self, l, r):
+            self.pose, self.intrinsics, self._r = l.pose, l.intrinsics, r
+
+        def get_rays(self):
+            return self._r
+    mine = [_Drawn(lidars[i], rays[i]) for i in range(b[rank], b[rank + 1])]
+    per = int(max(b[1:] - b[:-1]))
+    max_local = per * max(len(r) for r in rays) if rays else 0
+    if mine:
+        rec, off = engine.scan_lidars(mine, mesh, want=("t", "point3", "sem", "ins"))
+        keep = np.isfinite(rec["t"])
+        pts = rec["point3"][keep]
+        lab = rec["sem"][keep].astype(np.int32) | (rec["ins"][keep].astype(np.int32) << 16)
+        cnt = np.array([int(keep[off[i]:off[i + 1]].sum()) for i in range(len(off) - 1)], np.int64)
+    else:
+        pts, lab, cnt = np.zeros((0, 3), np.float32), np.zeros(0, np.int32), np.zeros(0, np.int64)
+    dev = device if device is not None else engine.torch_device()
+    g = CloudGather(max(max_local, 1), max(per, 1), dist, dev, group=group)
+    k = len(pts)
+    if k:
+        g.slab[:k, :3] = torch.from_numpy(pts).to(dev)
+        g.slab[:k, 3] = torch.from_numpy(lab).to(dev).view(torch.float32)
+    g.counts.zero_()
+    if len(cnt):
+        g.counts[:len(cnt)] = torch.from_numpy(cnt).to(dev)
+    g.gather()                                          # the ONE collective of the scan
+    P_all, L_all, C_all = g.assemble(torch.from_numpy(b[1:] - b[:-1]))
+    lab_all = L_all.cpu().numpy().view(np.uint32)
+    return {"point3": P_all.cpu().numpy(), "sem": (lab_all & 0xFFFF).astype(np.uint16),
+            "ins": (lab_all >> 16).astype(np.uint16), "counts": C_all.cpu().numpy().astype(np.int64),
+            "total": int(P_all.shape[0])}

@@ -33,20 +33,34 @@ def mesh_arrays(mesh):
     return v, f, (None if sem is None else np.asarray(sem)), (None if ins is None else np.asarray(ins))
 
 
-def _fingerprint(v, f):
+def _fingerprint(v, f, full=False):
+    """Cache key of a mesh's arrays.  ``full=False`` (the default on the per-waypoint call path, where the reference
+    calls the engine once per pose with the same mesh object) hashes both ends of each array plus 4096 rows spread
+    evenly over the whole of it: it costs microseconds and notices a replaced or re-generated mesh, but an in-place
+    edit of a few rows in the middle of a large array can escape it -- after editing a mesh in place call
+    ``engine.clear_cache()`` (or construct the engine with ``cache_check="full"``, which hashes every byte:
+    milliseconds per call on a million-triangle mesh)."""
     h = hashlib.blake2b(digest_size=16)
-    h.update(np.ascontiguousarray(v).view(np.uint8).reshape(-1)[:1 << 16].tobytes())
-    h.update(np.ascontiguousarray(f).view(np.uint8).reshape(-1)[:1 << 16].tobytes())
-    h.update(np.ascontiguousarray(v).view(np.uint8).reshape(-1)[-(1 << 16):].tobytes())
+    for a in (v, f):
+        a = np.ascontiguousarray(a)
+        b = a.view(np.uint8).reshape(-1)
+        if full or b.size <= (1 << 18):
+            h.update(b.tobytes())
+        else:
+            h.update(b[:1 << 16].tobytes())
+            h.update(b[-(1 << 16):].tobytes())
+            rows = a.reshape(len(a), -1)
+            h.update(np.ascontiguousarray(rows[::max(1, len(rows) // 4096)]).tobytes())
     return (v.shape, f.shape, str(v.dtype), str(f.dtype), h.hexdigest())
 
 
 class RaycastEngineHIP(RaycastEngineBase):
     """HIP (gfx950) engine.  ``RaycastEngineGPU`` is this class."""
 
-    def __init__(self, verbose=False, device=0, max_cached_scenes=4):
+    def __init__(self, verbose=False, device=0, max_cached_scenes=4, cache_check="sampled"):
         super().__init__()
         self.verbose = verbose
+        self.cache_check = cache_check      # "sampled" | "full": see _fingerprint
         self.ctx = Context(device)          # raises when there is no GPU / no library
         self._scenes = {}                   # id(mesh) -> (weakref or None, fingerprint, Scene)
         self._dir_tables = {}
@@ -56,7 +70,7 @@ class RaycastEngineHIP(RaycastEngineBase):
     def scene_for(self, mesh):
         v, f, sem, ins = mesh_arrays(mesh)
         key = id(mesh)
-        fp = _fingerprint(v, f)
+        fp = _fingerprint(v, f, full=self.cache_check == "full")
         ent = self._scenes.get(key)
         if ent is not None and ent[1] == fp and (ent[0] is None or ent[0]() is mesh):
             return ent[2]
@@ -162,6 +176,110 @@ class RaycastEngineHIP(RaycastEngineBase):
         P, N = poses.shape[0], dirs.shape[0]
         return {k: a.reshape((P, N) + a.shape[1:]) for k, a in out.items()}, N
 
+
+    def scan_frames(self, intrinsics, poses, mesh, want=("point3", "sem", "ins")):
+        """The whole trajectory straight to the reference's per-pose frames: scan + compaction stay in HBM, only the
+        kept rows cross PCIe, into page-locked buffers (lrc_scan_poses_compact).  Returns the dict of
+        lidarcast.Scene.scan_poses_compact: (K, ...) arrays in np.vstack order + ``counts`` (P,) + ``total``;
+        ``split_frames`` turns it into per-pose views.  What the per-waypoint loop of
+        s3dis_simulator.py:254-288 produces, for multi-line sensors."""
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 4, 4)
+        if not hasattr(intrinsics, "horizontal_res") or hasattr(intrinsics, "swing_amplitude"):
+            raise ValueError("sensor has no pose-independent direction table")
+        return self.scene_for(mesh).scan_poses_compact(poses, self._direction_table(intrinsics),
+                                                       intrinsics.max_range, want=want)
+
+    def scan_frames_dual_axis(self, lidars, mesh, want=("point3", "sem", "ins")):
+        """Opt-in fast path of the dual-axis sensor: the noisy scan angles and the dropout mask are drawn on the host
+        from the numpy stream, pose after pose, exactly as ``get_rays()`` would draw them (the seeded stream is the
+        reference's definition of the scan, lidar/indoor_lidar.py:262-294); trigonometry, rotation and the float32
+        narrowing happen in the kernel (lrc_scan_angles_compact).  Not bit-guaranteed against ``scan_lidars`` (device
+        vs host sin/cos); same return value as ``scan_frames``."""
+        if len(lidars) == 0:
+            raise ValueError("no lidars given")
+        k0 = lidars[0].intrinsics
+        n = k0.num_vertical_lines * (int(k0.point_rate * k0.scan_duration) // k0.num_vertical_lines)
+        ang = self.ctx.pinned.take(len(lidars) * n * 16)[:len(lidars) * n * 16].view(np.float64).reshape(len(lidars), n, 2)
+        keep = self.ctx.pinned.take(len(lidars) * n)[:len(lidars) * n].reshape(len(lidars), n)
+        keep[:] = 1
+        for i, l in enumerate(lidars):
+            phi, theta, k = l.scan_angles()
+            if phi.size != n:
+                raise ValueError("dual-axis poses must share one ray count")
+            ang[i, :, 0], ang[i, :, 1] = phi, theta
+            if k is not None:
+                keep[i] = k
+        poses = np.stack([np.asarray(l.pose, dtype=np.float64) for l in lidars])
+        return self.scene_for(mesh).scan_angles_compact(poses, ang, keep, lidars[0].intrinsics.max_range, want=want)
+
+    # ---- device steps of the N-rank scan (lidarcast.distributed.scan_frames_sharded) ----------------------
+    def torch_device(self):
+        import torch
+        return torch.device("cuda", self.ctx.device)
+
+    def prim_gather(self, poses_local, rays_per_pose, dist, group=None):
+        """Send / receive slabs of the per-scan all-gather, cached per shape (PrimGather)."""
+        from lidarcast.distributed import PrimGather
+        key = (int(poses_local), int(rays_per_pose), id(dist), id(group))
+        g = getattr(self, "_gathers", {}).get(key)
+        if g is None:
+            g = PrimGather(poses_local, rays_per_pose, dist, self.torch_device(), group=group)
+            self._gathers = {key: g}
+        return g
+
+    def scan_block_into(self, g, intrinsics, block_poses, mesh):
+        """Trace this rank's pose block; the kernel writes the hit triangle ids and the per-wave keep counts straight
+        into the gather's send slab.  A block shorter than the slab leaves invalid ids / zero counts behind."""
+        import torch
+        from lidarcast import DeviceHits
+        dev = self.torch_device()
+        scene = self.scene_for(mesh)
+        dirs = self._direction_table(intrinsics)
+        block_poses = np.ascontiguousarray(block_poses, dtype=np.float64).reshape(-1, 16)
+        p_loc, n = len(block_poses), len(dirs)
+        g.wait()
+        if p_loc < g.poses_local:
+            g.slab.fill_(-1)
+            if g.tile_count is not None:
+                g.tile_count.zero_()
+        if p_loc == 0:
+            return
+        want = ("prim", "tile_count") if g.fused_counts else ("prim",)
+        hits = DeviceHits(0, dev, want=())
+        hits.struct.prim = g.prim.data_ptr()
+        if g.fused_counts:
+            hits.struct.tile_count = g.tile_count.data_ptr()
+        d_poses = torch.from_numpy(block_poses).to(dev)
+        d_dirs = torch.from_numpy(np.ascontiguousarray(dirs)).to(dev)
+        scene.scan_poses_dev(d_poses, d_dirs, hits, intrinsics.max_range, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.current_stream().synchronize()       # the slab is complete before the collective reads it
+
+    def cloud_from_gather(self, g, intrinsics, padded_poses, mesh):
+        """Every rank's gathered ids -> the compacted (x, y, z, label) rows of ALL poses + per-pose counts, rebuilt
+        with the scan's own arithmetic (lrc_cloud_from_prims_dev), then ONE transfer of the kept rows."""
+        import torch
+        dev = self.torch_device()
+        scene = self.scene_for(mesh)
+        dirs = self._direction_table(intrinsics)
+        poses = np.ascontiguousarray(padded_poses, dtype=np.float64).reshape(-1, 16)
+        P, n = len(poses), len(dirs)
+        g.wait()
+        d_poses = torch.from_numpy(poses).to(dev)
+        d_dirs = torch.from_numpy(np.ascontiguousarray(dirs)).to(dev)
+        rows = torch.empty((P * n, 4), dtype=torch.float32, device=dev)
+        counts = torch.zeros(P, dtype=torch.int64, device=dev)
+        scene.cloud_from_prims_dev(d_poses, d_dirs, g.all_prims, rows, counts, g.all_tile_counts,
+                                   poses_per_slab=g.poses_local, slab_stride_bytes=g.stride_bytes,
+                                   stream=torch.cuda.current_stream().cuda_stream)
+        c = counts.cpu().numpy()
+        return rows[:int(c.sum())].cpu().numpy(), c
+
+    @staticmethod
+    def split_frames(frames, name):
+        """Per-pose views of one attribute of a scan_frames result (no copy)."""
+        ends = np.cumsum(frames["counts"])
+        a = frames[name]
+        return [a[e - c:e] for c, e in zip(frames["counts"], ends)]
 
     def scan_lidars(self, lidars, mesh, want=("t", "point3", "incident_deg")):
         """Several sensor poses whose rays come from the host generator (dual-axis sensor: seeded noise and

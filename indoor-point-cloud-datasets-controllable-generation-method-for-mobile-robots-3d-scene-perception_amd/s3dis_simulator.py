@@ -24,6 +24,9 @@ from raycast_engine import RaycastEngineCPU, RaycastEngineGPU
 from trajectory import AutoTrajectoryGenerator, PathType, SmartTrajectoryGenerator, Waypoint, poses_from_waypoints
 
 
+_NO_GROUP = object()     # run_simulation(process_group=_NO_GROUP): single-process scan even inside a distributed job
+
+
 class S3DISSimulator:
     def __init__(self, config: Dict[str, Any], use_dense_lidar: bool = False, use_blk2go: bool = False,
                  bug_compatible: bool = True):
@@ -133,9 +136,10 @@ class S3DISSimulator:
         return sim_scene
 
     # ---- the scan stage ---------------------------------------------------------------------------
-    def _quality(self, points, incident_angles, total_points_per_scan, room_volume) -> ScanQuality:
+    def _quality(self, points, incident_angles, total_points_per_scan, room_volume, ranges=None) -> ScanQuality:
         k = len(points)
-        ranges = np.linalg.norm(points, axis=1) if k > 0 else None     # from the world origin, as the reference
+        if ranges is None:
+            ranges = np.linalg.norm(points, axis=1) if k > 0 else None     # from the world origin, as the reference
         return ScanQuality(
             coverage_ratio=k / total_points_per_scan, num_points=k,
             incident_angle_mean=np.mean(incident_angles) if len(incident_angles) > 0 else 0,
@@ -143,7 +147,11 @@ class S3DISSimulator:
             scan_density=k / room_volume,
             range_mean=np.mean(ranges) if k > 0 else 0, range_std=np.std(ranges) if k > 0 else 0)
 
-    def run_simulation(self, waypoints: List[Waypoint]) -> S3DISSimScene:
+    def run_simulation(self, waypoints: List[Waypoint], process_group=None) -> S3DISSimScene:
+        """The scan stage (reference :220-296).  Inside an initialised ``torch.distributed`` job with more than one
+        rank (one process per GPU, backend "nccl" = RCCL), or with an explicit ``process_group``, the waypoints are
+        sharded over the ranks in contiguous blocks, ONE all-gather per scan assembles the scene, and every rank
+        returns the complete S3DISSimScene -- identical to the single-process result."""
         if self.scene is None:
             raise ValueError("Scene not loaded. Call load_scene() first.")
         if self.raycast_engine is None:
@@ -156,29 +164,60 @@ class S3DISSimulator:
         total = self.lidar_config.get_total_points_per_scan()
         volume = self.scene.room_bounds.get_volume()
 
+        # The whole trajectory in ONE launch; compaction into per-pose frames happens in HBM and only the kept rows
+        # cross PCIe, into page-locked buffers -- the frames below are views of those (lrc_scan_poses_compact).
+        # In bug-compatible mode the incident angles are overwritten with zeros anyway (reference :266-269), so they
+        # are not even transferred.  range_origin is |point| from the WORLD origin (reference :283-284), float32,
+        # formed on the device exactly as np.linalg.norm(points, axis=1) forms it.
+        engine = self.raycast_engine
+        want = ("point3", "sem", "ins", "range_origin") + (() if self.bug_compatible else ("incident_deg",))
         batched = isinstance(self.lidar_config, Indoor8LineLidarIntrinsics) and \
-            self.lidar_config.vertical_degrees is not None and len(waypoints) > 0
-        if batched:
-            # every pose in one launch; rays generated in the kernel
-            rec, n = self.raycast_engine.scan_poses(self.lidar_config, poses_from_waypoints(waypoints), mesh,
-                                                    want=("t", "point3", "incident_deg", "sem", "ins"))
-        elif len(waypoints) > 0:
-            # host-generated rays (dual-axis sensor): all poses in one launch, ragged segments
-            lidars = [create_lidar(self.lidar_config, wp.to_pose_matrix()) for wp in waypoints]
-            seg, off = self.raycast_engine.scan_lidars(lidars, mesh, want=("t", "point3", "incident_deg", "sem", "ins"))
-        for i, wp in enumerate(waypoints):
+            self.lidar_config.vertical_degrees is not None
+        device_gen = bool(self.config.get("raycast_engine", {}).get("device_ray_generation", False))
+        fr = None
+        from lidarcast.distributed import active_group, scan_frames_sharded, scan_lidars_sharded
+        dist, group = (None, None) if process_group is _NO_GROUP else active_group(process_group)
+        if dist is not None and len(waypoints) > 0:
             if batched:
-                keep = rec["t"][i] != np.inf
-                points, angles = rec["point3"][i][keep], rec["incident_deg"][i][keep]
-                sem, ins = rec["sem"][i][keep], rec["ins"][i][keep]
+                fr = scan_frames_sharded(engine, self.lidar_config, poses_from_waypoints(waypoints), mesh, dist, group)
+            else:
+                lidars = [create_lidar(self.lidar_config, wp.to_pose_matrix()) for wp in waypoints]
+                fr = scan_lidars_sharded(engine, lidars, mesh, dist, group)
+            # attributes the gathered rows do not carry are the reference's own numpy expressions of the points
+            ends = np.cumsum(fr["counts"])
+            fr["range_origin"] = np.linalg.norm(fr["point3"], axis=1) if fr["total"] else np.zeros(0, np.float32)
+            if not self.bug_compatible:
+                cen = np.repeat(np.stack([wp.to_pose_matrix()[:3, 3] for wp in waypoints]), fr["counts"], axis=0)
+                v = fr["point3"] - cen
+                v = v / np.linalg.norm(v, axis=1, keepdims=True)
+                fr["incident_deg"] = np.degrees(np.arccos(np.abs(v[:, 2])))      # raycast_engine_cpu.py:100-107
+        elif len(waypoints) > 0 and batched:
+            fr = engine.scan_frames(self.lidar_config, poses_from_waypoints(waypoints), mesh, want=want)
+        elif len(waypoints) > 0 and device_gen and isinstance(self.lidar_config, DualAxisLidarIntrinsics):
+            # opt-in: dual-axis rays generated in the kernel from the host-drawn scan angles
+            lidars = [create_lidar(self.lidar_config, wp.to_pose_matrix()) for wp in waypoints]
+            fr = engine.scan_frames_dual_axis(lidars, mesh, want=want)
+        elif len(waypoints) > 0:
+            # host-generated rays (dual-axis sensor, the bit-exact default): all poses in one launch, ragged segments
+            lidars = [create_lidar(self.lidar_config, wp.to_pose_matrix()) for wp in waypoints]
+            seg, off = engine.scan_lidars(lidars, mesh, want=("t", "point3", "incident_deg", "sem", "ins"))
+        if fr is not None:
+            pts_f, sem_f, ins_f = (engine.split_frames(fr, a) for a in ("point3", "sem", "ins"))
+            rng_f = engine.split_frames(fr, "range_origin")
+            ang_f = None if self.bug_compatible else engine.split_frames(fr, "incident_deg")
+        for i, wp in enumerate(waypoints):
+            if fr is not None:
+                points, sem, ins, ranges = pts_f[i], sem_f[i], ins_f[i], rng_f[i]
+                angles = np.zeros(len(points)) if self.bug_compatible else ang_f[i]
             else:
                 a, b = off[i], off[i + 1]
                 keep = seg["t"][a:b] != np.inf
                 points, angles = seg["point3"][a:b][keep], seg["incident_deg"][a:b][keep]
                 sem, ins = seg["sem"][a:b][keep], seg["ins"][a:b][keep]
-            if self.bug_compatible:
-                angles = np.zeros(len(points))            # reference :266-269
-            q = self._quality(points, angles, total, volume)
+                ranges = None
+                if self.bug_compatible:
+                    angles = np.zeros(len(points))            # reference :266-269
+            q = self._quality(points, angles, total, volume, ranges)
             sim_scene.append_frame(S3DISSimFrame(i, points, angles, q, semantic_labels=sem,
                                                  instance_labels=ins))
         sim_scene.compute_statistics(time.time() - start)
@@ -200,3 +239,74 @@ def load_default_config() -> Dict[str, Any]:
 
 def create_simulator_from_config(config_path: Optional[str] = None) -> S3DISSimulator:
     return S3DISSimulator(load_default_config() if config_path is None else load_config(config_path))
+
+
+def run_scene_batch(scenes, trajectories, sensor=None, config: Optional[Dict[str, Any]] = None,
+                    use_dense_lidar: bool = False, use_blk2go: bool = False, output_base_dir=None,
+                    process_group=None, skip_existing: bool = True) -> Dict[str, Any]:
+    """Several scenes through one simulator, the job of the reference's batch loop (s3dis_simulator.py:594-726:
+    per scene load -> trajectory -> run_simulation -> save_results, failures collected, finished scenes skipped) as
+    a function instead of a hard-coded ``main``.
+
+    scenes        list of (name, mesh object or PLY path)
+    trajectories  {name: waypoints (List[Waypoint]) or (P,4,4) poses}, or an int = waypoints planned per scene
+    sensor        optional intrinsics record replacing the simulator's default (e.g. a 32-line x 2048 sweep)
+    output_base_dir  results of scene ``name`` go to <dir>/<name>; a scene whose labelled cloud and statistics
+                  file exist is skipped (the reference's resume rule, :637-648)
+    Inside a torch.distributed job the scenes are dealt round-robin to the ranks (each scene is one rank's work, its
+    trajectory is not sharded again) and the per-scene summaries are gathered; ``sim_scene`` objects stay on the
+    rank that produced them.  Returns {"scenes": {name: {...}}, "failed": [...], "skipped": [...], "total_rays",
+    "seconds", "rays_per_s"} with seconds = the scan stages only (scene builds and file writing excluded)."""
+    from lidarcast.distributed import active_group
+    dist, group = active_group(process_group)
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist is not None else (0, 1)
+    sim = S3DISSimulator(config or {"raycast_engine": {"use_gpu": True}}, use_dense_lidar=use_dense_lidar,
+                         use_blk2go=use_blk2go)
+    if sensor is not None:
+        sim.lidar_config = sensor
+    done, failed, skipped = {}, [], []
+    rays_per_pose = sim.lidar_config.get_total_points_per_scan()
+    for i, (name, source) in enumerate(scenes):
+        if i % world != rank:
+            continue
+        out_dir = None if output_base_dir is None else Path(output_base_dir) / name
+        if (skip_existing and out_dir is not None and (out_dir / "combined_pointcloud_with_label.ply").exists()
+                and (out_dir / "simulation_statistics.txt").exists()):
+            skipped.append(name)
+            continue
+        try:
+            sim.load_scene(source, name)
+            traj = trajectories if isinstance(trajectories, int) else trajectories[name]
+            if isinstance(traj, int):
+                waypoints, _ = sim.generate_auto_trajectory(traj)
+            elif isinstance(traj, np.ndarray):
+                waypoints = [Waypoint(m[0, 3], m[1, 3], m[2, 3], yaw=float(np.arctan2(m[1, 0], m[0, 0])),
+                                      timestamp=float(k)) for k, m in enumerate(traj.reshape(-1, 4, 4))]
+            else:
+                waypoints = list(traj)
+            sim.raycast_engine.scene_for(sim.scene.room_mesh)        # scene build: outside the scan timing
+            t0 = time.perf_counter()
+            sim_scene = sim.run_simulation(waypoints, process_group=_NO_GROUP)
+            dt = time.perf_counter() - t0
+            if out_dir is not None:
+                sim.save_results(sim_scene, out_dir, waypoints)
+            done[name] = {"sim_scene": sim_scene, "frames": len(sim_scene.frames), "rays": len(waypoints) * rays_per_pose,
+                          "points": int(sim_scene.get_total_points()), "seconds": dt}
+        except Exception as e:                                       # noqa: BLE001 - the reference collects and goes on
+            failed.append((name, str(e)))
+    if dist is not None:
+        parts = [None] * world
+        summary = {k: {a: b for a, b in v.items() if a != "sim_scene"} for k, v in done.items()}
+        dist.all_gather_object(parts, (summary, failed, skipped), group=group)
+        for r, (sm, fl, sk) in enumerate(parts):
+            if r != rank:
+                done.update(sm)
+                failed += fl
+                skipped += sk
+        seconds = max(sum(v["seconds"] for v in part[0].values()) for part in parts)    # ranks work side by side
+    else:
+        seconds = sum(v["seconds"] for v in done.values())
+    total_rays = sum(v["rays"] for v in done.values())
+    order = [n for n, _ in scenes]
+    return {"scenes": {n: done[n] for n in order if n in done}, "failed": failed, "skipped": skipped, "ranks": world,
+            "total_rays": int(total_rays), "seconds": seconds, "rays_per_s": total_rays / seconds if seconds > 0 else 0.0}

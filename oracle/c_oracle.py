@@ -32,6 +32,12 @@ def load():
         lib.orc_bvh_free.restype = None
         lib.orc_cast_bvh.argtypes = [vp, vp, u64, vp, vp, C.c_int]
         lib.orc_cast_bvh.restype = None
+        lib.orc_cast_bvh_diag.argtypes = [vp, vp, u64, vp, vp, vp, C.c_int]
+        lib.orc_cast_bvh_diag.restype = None
+        lib.orc_witness_f64.argtypes = [vp, vp, u64, vp, vp, vp, C.c_int]
+        lib.orc_witness_f64.restype = None
+        lib.orc_witness_tri_f64.argtypes = [vp, vp, vp, vp, u64, vp, vp]
+        lib.orc_witness_tri_f64.restype = None
         lib.orc_normals.argtypes = [vp, vp, vp, u64, vp]
         lib.orc_normals.restype = None
         lib.orc_has_fma.restype = C.c_int
@@ -77,6 +83,37 @@ class OracleMesh:
         prim = np.empty(n, np.uint32)
         load().orc_cast_bvh(self._bvh, _p(rays), n, _p(t), _p(prim), int(threads))
         return t, prim
+
+    def cast_diag(self, rays, threads=1):
+        """(t, prim, pad_rejections): the cast plus, per ray, how many visited triangles were rejected by the
+        padded-box clause alone (the clause Embree does not have)."""
+        if self._bvh is None:
+            self.build()
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        n = len(rays)
+        t, prim, rej = np.empty(n, np.float32), np.empty(n, np.uint32), np.empty(n, np.uint32)
+        load().orc_cast_bvh_diag(self._bvh, _p(rays), n, _p(t), _p(prim), _p(rej), int(threads))
+        return t, prim, rej
+
+    def witness(self, rays, threads=1):
+        """float64 witness (textbook Moeller-Trumbore in double, no box clause): (t64, prim, margin) with
+        margin = min(u, v, 1-u-v) of the winning hit, -1 on a miss."""
+        if self._bvh is None:
+            self.build()
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        n = len(rays)
+        t, prim, m = np.empty(n, np.float64), np.empty(n, np.uint32), np.empty(n, np.float64)
+        load().orc_witness_f64(self._bvh, _p(rays), n, _p(t), _p(prim), _p(m), int(threads))
+        return t, prim, m
+
+    def witness_triangle(self, rays, prim):
+        """float64 test of the ONE triangle prim[i] per ray: (t64, margin), +inf / -1 where double says miss."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        prim = np.ascontiguousarray(prim, dtype=np.uint32)
+        n = len(rays)
+        t, m = np.empty(n, np.float64), np.empty(n, np.float64)
+        load().orc_witness_tri_f64(_p(self.v), _p(self.f), _p(rays), _p(prim), n, _p(t), _p(m))
+        return t, m
 
     def normals(self, prim):
         prim = np.ascontiguousarray(prim, dtype=np.uint32)

@@ -25,6 +25,10 @@
  * the lexicographic minimum of (t, triangle row).  orc_cast_brute evaluates it over all triangles;
  * orc_cast_bvh uses its own median-split BVH (not the product's SAH tree) and must agree exactly.
  *
+ * Also here: orc_witness_f64, an INDEPENDENT double-precision statement of the closest two-sided hit (textbook
+ * Moeller-Trumbore, no box clause), used by the tests to bound |t_float32 - t_exact| and to count rays on which the
+ * float32 definition and exact geometry disagree; and orc_cast_bvh_diag, which counts how often the box clause acts.
+ *
  * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -shared -fPIC -pthread).
  */
 #include <math.h>
@@ -106,8 +110,17 @@ ORC_INL int tri_hit(v3 o, v3 d, const slab_t* s, v3 v0, v3 v1, v3 v2, float* t_o
     lo[1] = min2(min2(v0.y, v1.y), v2.y); hi[1] = max2(max2(v0.y, v1.y), v2.y);
     lo[2] = min2(min2(v0.z, v1.z), v2.z); hi[2] = max2(max2(v0.z, v1.z), v2.z);
     slab_interval(s, lo, hi, &tn, &tf);
-    if (!((tn <= t) && (t <= tf) && (t < INFINITY))) return 0;
+    if (!((tn <= t) && (t <= tf) && (t < INFINITY))) return (t < INFINITY) ? -1 : 0;   /* -1: rejected by the pad clause alone */
     *t_out = t;
+    return 1;
+}
+
+/* finite-ray contract (include/lidarcast.h): a ray with a NaN or infinite component is never cast -- a miss */
+ORC_INL int finite_ray(const float* r) {
+    for (int k = 0; k < 6; ++k) {
+        uint32_t u; memcpy(&u, &r[k], 4);
+        if ((u & 0x7F800000u) == 0x7F800000u) return 0;
+    }
     return 1;
 }
 
@@ -128,10 +141,10 @@ void orc_cast_brute(const float* verts, const uint32_t* tris, uint64_t T,
         slab_t s = make_slab(o, d);
         float best = INFINITY;
         uint32_t bp = 0xFFFFFFFFu;
-        for (uint64_t k = 0; k < T; ++k) {
+        for (uint64_t k = 0; k < (finite_ray(r) ? T : 0); ++k) {
             float t;
             if (tri_hit(o, d, &s, vert(verts, tris[3 * k]), vert(verts, tris[3 * k + 1]),
-                        vert(verts, tris[3 * k + 2]), &t)) {
+                        vert(verts, tris[3 * k + 2]), &t) == 1) {
                 if (t < best || (t == best && (uint32_t)k < bp)) { best = t; bp = (uint32_t)k; }
             }
         }
@@ -249,16 +262,16 @@ void orc_bvh_free(orc_bvh* b) {
 
 ORC_CLONES
 static void cast_range(const orc_bvh* b, const float* rays6, uint64_t begin, uint64_t end,
-                       float* t_out, uint32_t* prim_out) {
+                       float* t_out, uint32_t* prim_out, uint32_t* pad_rej_out) {
     int32_t stack[128];
     for (uint64_t i = begin; i < end; ++i) {
         const float* r = rays6 + 6 * i;
         v3 o = {r[0], r[1], r[2]}, d = {r[3], r[4], r[5]};
         slab_t s = make_slab(o, d);
         float best = INFINITY;
-        uint32_t bp = 0xFFFFFFFFu;
+        uint32_t bp = 0xFFFFFFFFu, pad_rej = 0;
         int sp = 0;
-        if (b->T) stack[sp++] = 0;
+        if (b->T && finite_ray(r)) stack[sp++] = 0;
         while (sp) {
             const onode* n = &b->nodes[stack[--sp]];
             float tn, tf;
@@ -268,10 +281,13 @@ static void cast_range(const orc_bvh* b, const float* rays6, uint64_t begin, uin
                 for (uint32_t j = n->first; j < n->first + n->count; ++j) {
                     uint32_t k = b->order[j];
                     float t;
-                    if (tri_hit(o, d, &s, vert(b->verts, b->tris[3 * (size_t)k]),
-                                vert(b->verts, b->tris[3 * (size_t)k + 1]),
-                                vert(b->verts, b->tris[3 * (size_t)k + 2]), &t)) {
+                    int h = tri_hit(o, d, &s, vert(b->verts, b->tris[3 * (size_t)k]),
+                                    vert(b->verts, b->tris[3 * (size_t)k + 1]),
+                                    vert(b->verts, b->tris[3 * (size_t)k + 2]), &t);
+                    if (h == 1) {
                         if (t < best || (t == best && k < bp)) { best = t; bp = k; }
+                    } else if (h < 0) {
+                        ++pad_rej;
                     }
                 }
             } else {
@@ -281,23 +297,24 @@ static void cast_range(const orc_bvh* b, const float* rays6, uint64_t begin, uin
         }
         t_out[i] = best;
         prim_out[i] = bp;
+        if (pad_rej_out) pad_rej_out[i] = pad_rej;
     }
 }
 
 typedef struct {
-    const orc_bvh* b; const float* rays6; uint64_t begin, end; float* t; uint32_t* prim;
+    const orc_bvh* b; const float* rays6; uint64_t begin, end; float* t; uint32_t* prim; uint32_t* pad_rej;
+    double* t64; double* margin64;     /* witness jobs */
 } job_t;
 
 static void* job_main(void* p) {
     job_t* j = (job_t*)p;
-    cast_range(j->b, j->rays6, j->begin, j->end, j->t, j->prim);
+    cast_range(j->b, j->rays6, j->begin, j->end, j->t, j->prim, j->pad_rej);
     return NULL;
 }
 
 /* closest hit of N rays with `threads` pthreads (threads <= 1: in the calling thread) */
-void orc_cast_bvh(const orc_bvh* b, const float* rays6, uint64_t N, float* t_out, uint32_t* prim_out,
-                  int threads) {
-    if (threads <= 1 || N < 1024) { cast_range(b, rays6, 0, N, t_out, prim_out); return; }
+static void run_jobs(void* (*fn)(void*), job_t proto, uint64_t N, int threads) {
+    if (threads <= 1 || N < 1024) { proto.begin = 0; proto.end = N; fn(&proto); return; }
     if (threads > 256) threads = 256;
     pthread_t th[256];
     job_t jobs[256];
@@ -307,12 +324,126 @@ void orc_cast_bvh(const orc_bvh* b, const float* rays6, uint64_t N, float* t_out
         uint64_t a = (uint64_t)k * chunk, e = a + chunk;
         if (a >= N) break;
         if (e > N) e = N;
-        job_t j = {b, rays6, a, e, t_out, prim_out};
-        jobs[k] = j;
-        if (pthread_create(&th[k], NULL, job_main, &jobs[k]) != 0) { job_main(&jobs[k]); th[k] = 0; }
+        jobs[k] = proto;
+        jobs[k].begin = a; jobs[k].end = e;
+        if (pthread_create(&th[k], NULL, fn, &jobs[k]) != 0) { fn(&jobs[k]); th[k] = 0; }
         started = k + 1;
     }
     for (int k = 0; k < started; ++k) if (th[k]) pthread_join(th[k], NULL);
+}
+
+void orc_cast_bvh(const orc_bvh* b, const float* rays6, uint64_t N, float* t_out, uint32_t* prim_out,
+                  int threads) {
+    job_t j = {b, rays6, 0, 0, t_out, prim_out, NULL, NULL, NULL};
+    run_jobs(job_main, j, N, threads);
+}
+
+/* the same cast, plus per ray the number of triangles it visited that pass every Moeller-Trumbore condition
+ * (den != 0, U,V >= 0, U+V <= |den|, T > 0, t finite) and are rejected ONLY by the clause "t inside the padded slab
+ * interval of the triangle's own box" -- the one clause of the hit definition Embree does not have.  The count
+ * depends on the traversal (culled subtrees are not visited); a total of 0 means the clause never acted. */
+void orc_cast_bvh_diag(const orc_bvh* b, const float* rays6, uint64_t N, float* t_out, uint32_t* prim_out,
+                       uint32_t* pad_rej_out, int threads) {
+    job_t j = {b, rays6, 0, 0, t_out, prim_out, pad_rej_out, NULL, NULL};
+    run_jobs(job_main, j, N, threads);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * float64 witness: an INDEPENDENT statement of "closest two-sided hit" -- the textbook Moeller-Trumbore test
+ * (edges from v0, barycentrics by division, no sign trick, no box clause) evaluated in double precision on the
+ * float32 vertices and the float32 ray.  It shares nothing with tri_hit above but the mesh and the BVH topology
+ * (boxes are re-tested in double, padded by 1e-9).  Tests use it to bound |t_float32 - t_exact| and to count rays on
+ * which the float32 definition and double-precision geometry disagree about hit/miss or about the triangle.
+ * margin = min(u, v, 1-u-v) of the winning hit (barycentric distance from the nearest edge), -1 on a miss.
+ * ---------------------------------------------------------------------------------------------- */
+static int tri_hit_f64(const double o[3], const double d[3], const float* a, const float* b_, const float* c,
+                       double* t_out, double* margin_out) {
+    double e1[3], e2[3], p[3], s[3], q[3];
+    for (int k = 0; k < 3; ++k) { e1[k] = (double)b_[k] - a[k]; e2[k] = (double)c[k] - a[k]; s[k] = o[k] - a[k]; }
+    p[0] = d[1] * e2[2] - d[2] * e2[1]; p[1] = d[2] * e2[0] - d[0] * e2[2]; p[2] = d[0] * e2[1] - d[1] * e2[0];
+    double det = e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2];
+    if (det == 0.0) return 0;
+    double inv = 1.0 / det;
+    double u = (s[0] * p[0] + s[1] * p[1] + s[2] * p[2]) * inv;
+    q[0] = s[1] * e1[2] - s[2] * e1[1]; q[1] = s[2] * e1[0] - s[0] * e1[2]; q[2] = s[0] * e1[1] - s[1] * e1[0];
+    double v = (d[0] * q[0] + d[1] * q[1] + d[2] * q[2]) * inv;
+    double t = (e2[0] * q[0] + e2[1] * q[1] + e2[2] * q[2]) * inv;
+    if (!(u >= 0.0 && v >= 0.0 && u + v <= 1.0 && t > 0.0 && t < INFINITY)) return 0;
+    double w = 1.0 - u - v, m = u < v ? u : v;
+    *t_out = t;
+    *margin_out = m < w ? m : w;
+    return 1;
+}
+
+static int box_hit_f64(const double o[3], const double d[3], const float* lo, const float* hi, double best) {
+    double tn = 0.0, tf = best;
+    for (int k = 0; k < 3; ++k) {
+        double l = (double)lo[k] - 1e-9, h = (double)hi[k] + 1e-9;
+        if (d[k] == 0.0) { if (o[k] < l || o[k] > h) return 0; continue; }
+        double t0 = (l - o[k]) / d[k], t1 = (h - o[k]) / d[k];
+        if (t0 > t1) { double x = t0; t0 = t1; t1 = x; }
+        if (t0 > tn) tn = t0;
+        if (t1 < tf) tf = t1;
+    }
+    return tn <= tf * (1.0 + 1e-12) + 1e-12;
+}
+
+static void* witness_main(void* p) {
+    job_t* j = (job_t*)p;
+    const orc_bvh* b = j->b;
+    int32_t stack[128];
+    for (uint64_t i = j->begin; i < j->end; ++i) {
+        const float* r = j->rays6 + 6 * i;
+        double o[3] = {r[0], r[1], r[2]}, d[3] = {r[3], r[4], r[5]};
+        double best = INFINITY, bm = -1.0;
+        uint32_t bp = 0xFFFFFFFFu;
+        int sp = 0;
+        if (b->T && finite_ray(r)) stack[sp++] = 0;
+        while (sp) {
+            const onode* n = &b->nodes[stack[--sp]];
+            if (!box_hit_f64(o, d, n->lo, n->hi, best)) continue;
+            if (n->count) {
+                for (uint32_t q = n->first; q < n->first + n->count; ++q) {
+                    uint32_t k = b->order[q];
+                    double t, m;
+                    if (tri_hit_f64(o, d, b->verts + 3 * (size_t)b->tris[3 * (size_t)k],
+                                    b->verts + 3 * (size_t)b->tris[3 * (size_t)k + 1],
+                                    b->verts + 3 * (size_t)b->tris[3 * (size_t)k + 2], &t, &m)) {
+                        if (t < best || (t == best && k < bp)) { best = t; bp = k; bm = m; }
+                    }
+                }
+            } else {
+                stack[sp++] = n->right;
+                stack[sp++] = n->left;
+            }
+        }
+        j->t64[i] = best;
+        j->prim[i] = bp;
+        if (j->margin64) j->margin64[i] = bm;
+    }
+    return NULL;
+}
+
+void orc_witness_f64(const orc_bvh* b, const float* rays6, uint64_t N, double* t_out, uint32_t* prim_out,
+                     double* margin_out, int threads) {
+    job_t j = {b, rays6, 0, 0, NULL, prim_out, NULL, t_out, margin_out};
+    run_jobs(witness_main, j, N, threads);
+}
+
+/* the witness test of ONE named triangle per ray (prim[i], 0xFFFFFFFF = skip): t and margin of that triangle alone,
+ * +inf / -1 when double precision says the ray misses it.  Used to ask "what does exact geometry say about the
+ * triangle the float32 definition chose". */
+void orc_witness_tri_f64(const float* verts, const uint32_t* tris, const float* rays6, const uint32_t* prim,
+                         uint64_t N, double* t_out, double* margin_out) {
+    for (uint64_t i = 0; i < N; ++i) {
+        t_out[i] = INFINITY; margin_out[i] = -1.0;
+        if (prim[i] == 0xFFFFFFFFu) continue;
+        const float* r = rays6 + 6 * i;
+        double o[3] = {r[0], r[1], r[2]}, d[3] = {r[3], r[4], r[5]}, t, m;
+        size_t k = prim[i];
+        if (tri_hit_f64(o, d, verts + 3 * (size_t)tris[3 * k], verts + 3 * (size_t)tris[3 * k + 1],
+                        verts + 3 * (size_t)tris[3 * k + 2], &t, &m)) { t_out[i] = t; margin_out[i] = m; }
+    }
 }
 
 /* unit geometric normal of triangle rows prim[i] (0 for 0xFFFFFFFF): Ng / sqrt(Ng.Ng) */

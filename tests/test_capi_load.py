@@ -13,7 +13,7 @@ def test_header_and_library_agree():
     from lidarcast import _capi
     hdr = open(os.path.join(REPO, "include", "lidarcast.h")).read()
     declared = set(re.findall(r"\b(lrc_[a-z_0-9]+)\s*\(", hdr))
-    declared -= {"lrc_hits", "lrc_compact_io", "lrc_scene_info"}
+    declared -= {"lrc_hits", "lrc_compact_io", "lrc_scene_info", "lrc_frames"}
     assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
     lib = lidarcast.load()
     for name in declared:
@@ -24,7 +24,7 @@ def test_header_and_library_agree():
 
 def test_struct_layouts_match_header():
     import ctypes as C
-    from lidarcast._capi import LrcCompactIO, LrcHits, LrcSceneInfo
+    from lidarcast._capi import LrcCompactIO, LrcFrames, LrcHits, LrcSceneInfo
     from conftest import REPO
 
     def header_fields(struct):
@@ -36,7 +36,9 @@ def test_struct_layouts_match_header():
     assert [n for n, _ in LrcHits._fields_] == header_fields("lrc_hits")          # all pointers, same order
     assert C.sizeof(LrcHits) == 10 * 8
     assert [n for n, _ in LrcCompactIO._fields_] == header_fields("lrc_compact_io")
-    assert C.sizeof(LrcCompactIO) == 13 * 8
+    assert C.sizeof(LrcCompactIO) == 14 * 8
+    assert [n for n, _ in LrcFrames._fields_] == header_fields("lrc_frames")
+    assert C.sizeof(LrcFrames) == 8 * 8
     assert C.sizeof(LrcSceneInfo) == 5 * 8 + 2 * 4 + 8 + 2 * 8 + 6 * 4
 
 

@@ -1,0 +1,398 @@
+"""-m gpu: the BASELINE configurations at their stated sizes (C3 witness, C4, C5), the frame-producing entry points
+of the plugin surface (lrc_scan_poses_compact, lrc_scan_angles_compact), the diagnostics (box-clause counter,
+float64 witness) and the rank-aware simulator, all through the C ABI.
+
+Oracle legs compare bit for bit with oracle/ (CPU restatement); the float64 witness (oracle/lrc_oracle.c,
+orc_witness_f64) is an independent double-precision statement of the closest hit that bounds what the float32
+definition can differ from exact geometry -- the honest parity statement against
+/root/reference/raycast_engine/raycast_engine_cpu.py:51, whose Embree arithmetic cannot run here."""
+import hashlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from helpers import assert_bit_equal, pose, sensor_32x2048, sensor_8x512, sensor_small
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from raycast_engine import RaycastEngineGPU
+    e = RaycastEngineGPU()
+    yield e
+    e.clear_cache()
+
+
+def _line_poses(name, n):
+    from lidarcast import synth
+    from trajectory import line_trajectory, poses_from_waypoints
+    Lx, Ly, _ = synth.SCENES[name]["size"]
+    return poses_from_waypoints(line_trajectory((1.0, Ly / 2, 1.0), (Lx - 1.0, Ly / 2, 1.0), n))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+# ---- plugin surface: scan straight to frames -------------------------------------------------------------------
+def test_scan_frames_equals_fixed_stride_records(engine):
+    """lrc_scan_poses_compact (scan + compaction in HBM, kept rows into page-locked buffers) == the fixed-stride
+    records of lrc_scan_poses masked on the host, attribute by attribute, incl. ragged widths and the world-origin
+    range column; the pinned pages are recycled once the caller drops the frames."""
+    from lidarcast import synth
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=4, seed=5, cell=0.05)
+    for k in (sensor_small(lines=5, width=200, max_range=2.2), sensor_small(lines=4, width=128, max_range=30.0)):
+        poses = np.stack([pose(0.8 + 0.5 * i, 1.4, 1.0, 0.3 * i) for i in range(5)])
+        rec, n = engine.scan_poses(k, poses, mesh, want=("t", "point3", "incident_deg", "sem", "ins"))
+        fr = engine.scan_frames(k, poses, mesh, want=("point3", "sem", "ins", "incident_deg", "index", "xyzl",
+                                                      "range_origin"))
+        keep = np.isfinite(rec["t"])
+        assert np.array_equal(fr["counts"], keep.sum(1)) and fr["total"] == keep.sum() > 100
+        assert 0 < keep.mean() < 1 or k.max_range > 10
+        assert_bit_equal(fr["point3"], rec["point3"][keep])
+        assert_bit_equal(fr["incident_deg"], rec["incident_deg"][keep])
+        assert np.array_equal(fr["sem"], rec["sem"][keep]) and np.array_equal(fr["ins"], rec["ins"][keep])
+        assert np.array_equal(fr["index"], np.concatenate([np.flatnonzero(m) for m in keep]))
+        assert_bit_equal(fr["xyzl"][:, :3].copy(), rec["point3"][keep])
+        lab = fr["xyzl"][:, 3].copy().view(np.uint32)
+        assert np.array_equal(lab, rec["sem"][keep].astype(np.uint32) | (rec["ins"][keep].astype(np.uint32) << 16))
+        assert_bit_equal(fr["range_origin"], np.linalg.norm(rec["point3"][keep], axis=1))
+        views = engine.split_frames(fr, "point3")
+        assert len(views) == 5 and all(np.shares_memory(v, fr["point3"]) or len(v) == 0 for v in views)
+        assert_bit_equal(views[3], rec["point3"][3][keep[3]])
+    # page-locked buffers: a second scan after the first result was dropped allocates nothing new
+    scene = engine.scene_for(mesh)
+    dirs = engine._direction_table(k)
+    a = scene.scan_poses_compact(poses, dirs, k.max_range)
+    before = engine.ctx.pinned.allocations
+    del a, fr, views
+    b = scene.scan_poses_compact(poses, dirs, k.max_range)
+    assert engine.ctx.pinned.allocations == before
+    # a result the caller still holds is never overwritten by the next scan
+    snap = b["point3"].copy()
+    c = scene.scan_poses_compact(poses[::-1].copy(), dirs, k.max_range)
+    assert_bit_equal(b["point3"], snap) and c["total"] == b["total"]
+    # too small a buffer: an error that names the size needed, nothing written past the buffer
+    with pytest.raises(ValueError, match="capacity"):
+        scene.scan_poses_compact(poses, dirs, k.max_range, capacity=10)
+    # no poses / no rays
+    assert scene.scan_poses_compact(np.zeros((0, 4, 4)), dirs, 5.0)["total"] == 0
+
+
+def test_nonfinite_rays_are_misses(engine):
+    """Finite-ray contract of the C ABI: a NaN / infinite component makes the ray a miss, like the oracle."""
+    from lidarcast import synth
+    from oracle.c_oracle import OracleMesh
+    cube = synth.unit_cube()
+    rays = np.random.default_rng(3).normal(size=(256, 6)).astype(np.float32)
+    rays[:, :3] *= 0.2
+    rays[::4, 0] = np.nan
+    rays[1::4, 4] = np.inf
+    rays[2::4, 5] = -np.inf
+    out = engine.cast_rays(rays, cube)
+    t, prim = OracleMesh(cube.vertices, cube.triangles).cast(rays)
+    sick = ~np.isfinite(rays).all(1)
+    assert sick.sum() == 192 and np.isinf(out["t_hit"][sick]).all() and (out["primitive_ids"][sick] == 0xFFFFFFFF).all()
+    assert not out["points"][sick].any() and np.isfinite(out["t_hit"][~sick]).all()
+    assert_bit_equal(out["t_hit"], t)
+    assert_bit_equal(out["primitive_ids"], prim)
+
+
+# ---- the hit definition against an independent witness -------------------------------------------------------
+def test_c3_rays_against_the_float64_witness(engine):
+    """>= 10^5 rays of the C3 workload: the HIP float32 result against double-precision Moeller-Trumbore over the
+    whole mesh.  Asserts the north-star tolerance |t32 - t64| <= 1e-5 m on every ray, the same triangle except on a
+    shared edge, and counts the rays on which float32 and exact geometry disagree about hit / miss (edge leaks)."""
+    import bench
+    from lidar import create_lidar
+    from lidarcast import synth
+    from oracle.c_oracle import OracleMesh
+    mesh = synth.make_scene(bench.SCENE)
+    sensor = bench.c3_sensor()
+    poses = bench.c3_poses(0, 1)[[0, 31, 63]]
+    rec, n = engine.scan_poses(sensor, poses, mesh, want=("t", "prim"))
+    t32, p32 = rec["t"].reshape(-1), rec["prim"].reshape(-1)
+    rays = np.concatenate([create_lidar(sensor, m).get_rays() for m in poses])
+    assert len(rays) == 196608
+    om = OracleMesh(mesh.vertices, mesh.triangles).build()
+    t64, p64, m64 = om.witness(rays, threads=16)
+    h32, h64 = np.isfinite(t32), np.isfinite(t64)       # max_range 25 m never cuts in this 5 m room
+    leaks_in, leaks_out = int((h64 & ~h32).sum()), int((h32 & ~h64).sum())
+    both = h32 & h64
+    dt = np.abs(t32[both].astype(np.float64) - t64[both])
+    other = both & (p32 != p64)
+    print(f"\n[witness] rays {len(rays)}: both hit {int(both.sum())}, both miss {int((~h32 & ~h64).sum())} (seams of the "
+          f"synthetic room), f64-hit/f32-miss {leaks_in}, f32-hit/f64-miss {leaks_out}, other triangle {int(other.sum())}, "
+          f"max |dt| {dt.max():.3e} m, p99.9 {np.percentile(dt, 99.9):.3e} m, mean {dt.mean():.3e} m")
+    assert dt.max() <= 1e-5
+    assert leaks_in + leaks_out <= 4                    # measured: 0
+    assert (m64[other] < 1e-4).all() and other.sum() <= 20
+    # the misses of this closed room are gaps of the mesh, not of the arithmetic: exact geometry misses too
+    assert ((~h32) == (~h64)).all() or leaks_in + leaks_out > 0
+
+
+def test_box_clause_never_acts_on_the_baseline_configs(engine):
+    """The hit definition's one clause Embree does not have (t inside the padded slab interval of the triangle's own
+    box) rejects nothing on C1/C2, C3 and the C5 scenes: instrumented trace kernel, counter [4] of
+    lrc_debug_scan_stats; C4's explicit rays through the oracle's counter."""
+    import bench
+    from lidar import DualAxisLidarIntrinsics, create_lidar
+    from lidarcast import synth
+    from oracle.c_oracle import OracleMesh
+    total = {}
+    a1 = synth.make_scene("synth_A1_office")
+    sc = engine.scene_for(a1)
+    k8 = sensor_8x512()
+    st = sc.scan_stats(pose(4.0, 3.0, 1.0)[None], engine._direction_table(k8), k8.max_range)
+    total["C1/C2"] = int(st[:, 4].sum())
+    assert st[:, 0].mean() > 10 and st[:, 1].mean() > 1          # the counters count
+    np.random.seed(0)
+    rays = create_lidar(DualAxisLidarIntrinsics.create_blk2go_dual_axis(), pose(2.0, 3.0, 1.0)).get_rays()
+    total["C4"] = int(OracleMesh(a1.vertices, a1.triangles).cast_diag(rays, threads=16)[2].sum())
+    sensor = bench.c3_sensor()
+    dirs = engine._direction_table(sensor)
+    for name in synth.SCENES:
+        mesh = a1 if name == "synth_A1_office" else synth.make_scene(name)
+        sc = engine.scene_for(mesh)
+        st = sc.scan_stats(_line_poses(name, 64)[::21], dirs, sensor.max_range)
+        total[name] = int(st[:, 4].sum())
+        if name == bench.SCENE:
+            uni = st[:, 2].sum() / st[:, 0].sum()
+            assert 0.3 < uni < 0.6                               # share of node steps on the scalar path
+    print("\n[box clause] rejections:", total)
+    assert all(v == 0 for v in total.values()), total
+
+
+# ---- C5: six scenes ------------------------------------------------------------------------------------------
+def test_c5_six_scenes_full_size(engine):
+    """BASELINE config C5: the C3 sensor x 64 poses over synth_A1..A6 through the plugin surface
+    (S3DISSimulator.run_simulation -> lrc_scan_poses_compact).  Every ray of every scene through size-independent
+    properties; two poses per scene ray by ray against the oracle; per-scene Chamfer distance (definition of
+    evaluate_single_scene.py:81-96, evaluated on the full clouds of those poses with lrc_min_distances) between the
+    HIP cloud and the oracle cloud == 0.0."""
+    import bench
+    from lidar import create_lidar
+    from lidarcast import synth
+    from lidarcast.metrics import min_distances
+    from oracle import np_oracle
+    from oracle.c_oracle import OracleMesh
+    from s3dis_simulator import run_scene_batch
+    sensor = bench.c3_sensor()
+    names = list(synth.SCENES)
+    meshes = {n: synth.make_scene(n) for n in names}
+    report = run_scene_batch([(n, meshes[n]) for n in names], {n: _line_poses(n, 64) for n in names},
+                             sensor=sensor, config={"raycast_engine": {"use_gpu": True}})
+    assert set(report["scenes"]) == set(names) and report["total_rays"] == 6 * 64 * 65536
+    for name in names:
+        mesh, sim = meshes[name], report["scenes"][name]["sim_scene"]
+        poses = _line_poses(name, 64)
+        assert len(sim.frames) == 64
+        counts = np.array([len(f.points) for f in sim.frames])
+        assert counts.min() > 0.99 * 65536 and counts.max() <= 65536
+        cloud = sim.combined_points()
+        lo, hi = mesh.vertices.min(0) - 1e-3, mesh.vertices.max(0) + 1e-3
+        assert cloud.dtype == np.float32 and len(cloud) == counts.sum()
+        assert (cloud >= lo).all() and (cloud <= hi).all()                      # every return lies in the room
+        sem = np.concatenate([f.semantic_labels for f in sim.frames])
+        assert set(np.unique(sem)) <= {0, 1, 2, 7, 8, 10} and (sem == 2).mean() > 0.2
+        om = OracleMesh(mesh.vertices, mesh.triangles).build()
+        ref, mine = [], []
+        for p in (5, 58):
+            lidar = create_lidar(sensor, poses[p])
+            rp, _, ridx = np_oracle.lidar_intersect_mesh(om, lidar, threads=16, return_index=True)
+            assert_bit_equal(sim.frames[p].points, rp, f"{name} pose {p}")
+            _, prim = om.cast(lidar.get_rays(), threads=16)
+            assert np.array_equal(sim.frames[p].semantic_labels, mesh.triangle_sem[prim[ridx]])
+            ref.append(rp)
+            mine.append(sim.frames[p].points)
+        ref, mine = np.concatenate(ref), np.concatenate(mine)
+        cd = float(np.mean(min_distances(mine, ref, engine.ctx)) + np.mean(min_distances(ref, mine, engine.ctx)))
+        assert cd == 0.0, (name, cd)
+        om.free()
+    print("\n[C5]", {k: v for k, v in report.items() if k != "scenes"})
+    assert report["rays_per_s"] > 2e7
+
+
+# ---- C4: BLK2GO, 256 poses -----------------------------------------------------------------------------------
+def _c4_hash(points, sem, ins, counts):
+    h = hashlib.sha256()
+    for a in (points, sem, ins, counts):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def test_c4_blk2go_256_poses_and_two_rank_gather(engine, tmp_path):
+    """BASELINE config C4 as stated: create_blk2go_dual_axis, np.random.seed(0) once, 256 poses on a line through
+    synth_A1_office, ONE lrc_cast_segments launch per rank; a sample of poses ray by ray against the oracle; then the
+    same job as a 2-rank launch (torch.distributed.run, gloo, both ranks on this one GPU) through
+    S3DISSimulator.run_simulation: SHA-256 of the assembled scene equal to the 1-rank run's."""
+    from lidar import DualAxisLidarIntrinsics, create_lidar
+    from lidarcast import synth
+    from oracle import np_oracle
+    from oracle.c_oracle import OracleMesh
+    from s3dis_simulator import S3DISSimulator
+    from trajectory import line_trajectory
+    mesh = synth.make_scene("synth_A1_office")
+    wps = line_trajectory((1.0, 3.0, 1.0), (7.0, 3.0, 1.0), 256)
+    sim = S3DISSimulator({"raycast_engine": {"use_gpu": True}}, use_blk2go=True)
+    sim.raycast_engine = engine
+    sim.load_scene(mesh, "synth_A1_office")
+    np.random.seed(0)
+    scene = sim.run_simulation(wps)
+    launches, rays_cast = engine.scene_for(mesh).counters()
+    counts = np.array([len(f.points) for f in scene.frames])
+    assert len(scene.frames) == 256 and 0.97 * 64000 * 0.98 < counts.mean() < 64000
+    one_rank = _c4_hash(scene.combined_points(), *scene.combined_labels(), counts)
+    # the oracle on the same seeded stream: poses 0, 100 and 255 (the stream is sequential: draw all, keep three)
+    kd = DualAxisLidarIntrinsics.create_blk2go_dual_axis()
+    om = OracleMesh(mesh.vertices, mesh.triangles).build()
+    np.random.seed(0)
+    for i, wp in enumerate(wps):
+        lidar = create_lidar(kd, wp.to_pose_matrix())
+        if i in (0, 100, 255):
+            rp, _ = np_oracle.lidar_intersect_mesh(om, lidar, threads=16)        # draws this pose's rays
+            assert_bit_equal(scene.frames[i].points, rp, f"pose {i}")
+        else:
+            lidar.get_rays()
+    # two ranks on the one GPU, launched the way the driver launches bench.py
+    out = tmp_path / "c4.json"
+    env = dict(os.environ, LRC_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(REPO, "tests", "configs", "run_simulation_ranks.py"), "c4", str(out)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.loads(out.read_text())
+    assert got["world"] == 2 and got["frames"] == 256
+    assert got["sha256"] == [one_rank, one_rank], "the 2-rank scene differs from the 1-rank scene"
+
+
+def test_run_simulation_two_ranks_multiline(engine, tmp_path):
+    """The rank-aware plugin surface for the multi-line sensor: S3DISSimulator.run_simulation inside a 2-rank
+    torch.distributed job (PrimGather: one all-gather of triangle ids, cloud rebuilt on every rank) returns on EVERY
+    rank the scene a single process returns: points, labels and frame sizes hash-identical (13 poses: ragged blocks)."""
+    from lidarcast import synth
+    from s3dis_simulator import S3DISSimulator
+    from trajectory import line_trajectory
+    mesh = synth.make_room(size=(5, 4, 3), num_boxes=6, seed=6, cell=0.04)
+    sim = S3DISSimulator({"raycast_engine": {"use_gpu": True}}, use_dense_lidar=True)
+    sim.raycast_engine = engine
+    sim.load_scene(mesh, "room")
+    scene = sim.run_simulation(line_trajectory((1.0, 2.0, 1.0), (4.0, 2.0, 1.0), 13, yaw=0.4))
+    counts = np.array([len(f.points) for f in scene.frames])
+    want = _c4_hash(scene.combined_points(), *scene.combined_labels(), counts)
+    out = tmp_path / "ml.json"
+    env = dict(os.environ, LRC_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(REPO, "tests", "configs", "run_simulation_ranks.py"), "multiline", str(out)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.loads(out.read_text())
+    assert got["world"] == 2 and got["frames"] == 13 and got["sha256"] == [want, want]
+    assert got["quality"] == [[f.scan_quality.num_points, float(f.scan_quality.range_mean)] for f in scene.frames][:3]
+
+
+# ---- dual-axis rays generated on the device (opt-in) ------------------------------------------------------------
+def test_dual_axis_device_generation(engine):
+    """lrc_scan_angles_compact: scan angles drawn on the host from the seeded stream, trigonometry + rotation in the
+    kernel.  Reports how many float32 directions differ from the host generator's and the largest range difference
+    on rays both paths return; the frames must agree to 1e-5 m and the stream must end where get_rays() leaves it."""
+    from lidar import DualAxisLidarIntrinsics, create_lidar
+    from lidarcast import synth
+    mesh = synth.make_room(size=(6, 5, 3), num_boxes=8, seed=2, cell=0.04)
+    kd = DualAxisLidarIntrinsics.create_blk2go_dual_axis()
+    poses = [pose(1.0 + 0.5 * i, 2.5, 1.0, 0.25 * i) for i in range(6)]
+    np.random.seed(5)
+    lid = [create_lidar(kd, m) for m in poses]
+    rec, off = engine.scan_lidars(lid, mesh, want=("t", "point3", "sem", "ins", "incident_deg"))
+    end_host = np.random.random()
+    np.random.seed(5)
+    fr = engine.scan_frames_dual_axis([create_lidar(kd, m) for m in poses], mesh,
+                                      want=("point3", "sem", "ins", "incident_deg", "index"))
+    assert np.random.random() == end_host                        # same number of draws consumed
+    keep = np.isfinite(rec["t"])
+    host_counts = np.array([int(keep[off[i]:off[i + 1]].sum()) for i in range(6)])
+    n_diff_sets, worst = 0, 0.0
+    ends = np.cumsum(fr["counts"])
+    for i in range(6):
+        a = rec["point3"][off[i]:off[i + 1]][keep[off[i]:off[i + 1]]]
+        b = fr["point3"][ends[i] - fr["counts"][i]:ends[i]]
+        if len(a) == len(b):
+            d = np.abs(a.astype(np.float64) - b).max()
+            same = np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        else:                     # a ray flipped between hit and miss: compare through the nearest points
+            d, same = 0.0, False
+        n_diff_sets += not same
+        worst = max(worst, d)
+    frac = np.abs(fr["counts"] - host_counts).sum() / host_counts.sum()
+    print(f"\n[dual-axis device generation] poses whose frames differ in any bit: {n_diff_sets}/6, "
+          f"largest coordinate difference {worst:.3e} m, hit-count difference {frac:.2e}")
+    assert frac <= 1e-4 and worst <= 1e-5
+    assert fr["total"] > 6 * 60000
+    # through the simulator: opt-in switch, same frames as the direct call
+    from s3dis_simulator import S3DISSimulator
+    from trajectory import Waypoint
+    sim = S3DISSimulator({"raycast_engine": {"use_gpu": True, "device_ray_generation": True}}, use_blk2go=True)
+    sim.raycast_engine = engine
+    sim.load_scene(mesh, "room")
+    np.random.seed(5)
+    sc = sim.run_simulation([Waypoint(m[0, 3], m[1, 3], m[2, 3], yaw=0.25 * i) for i, m in enumerate(poses)])
+    assert [len(f.points) for f in sc.frames] == fr["counts"].tolist()
+    assert_bit_equal(sc.combined_points(), fr["point3"])
+
+
+# ---- labels from annotation files through the simulator (advisor finding) ---------------------------------------
+def test_simulator_export_reads_the_annotation_files(tmp_path, engine):
+    """S3DISSimulator configured with s3dis_data_root / area / room, as the reference wires it
+    (containers/s3dis_sim_scene.py:379-427): run_simulation attaches the hit triangles' labels to every frame, and
+    save_results must STILL take colours and labels from the annotation files on disk (nearest annotated point)."""
+    from sklearn.neighbors import NearestNeighbors
+    from containers import read_labeled_ply
+    from lidarcast import synth
+    from s3dis_annotation_loader import S3DISAnnotationLoader
+    from s3dis_simulator import S3DISSimulator
+    from trajectory import line_trajectory
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=2, seed=3, cell=0.08)
+    rng = np.random.default_rng(1)
+    room = tmp_path / "data" / "Area_7" / "office_3"
+    (room / "Annotations").mkdir(parents=True)
+    raw = []
+    for name, n in (("wall_1", 4000), ("floor_1", 2500), ("chair_1", 800), ("table_1", 900), ("ceiling_1", 2000)):
+        tri = mesh.triangles[rng.integers(0, len(mesh.triangles), n)]
+        w = rng.dirichlet([1, 1, 1], n)
+        pts = (mesh.vertices[tri] * w[:, :, None]).sum(1)
+        rgb = rng.integers(0, 256, (n, 3))
+        np.savetxt(room / "Annotations" / f"{name}.txt", np.hstack([pts, rgb]), fmt="%.6f %.6f %.6f %d %d %d")
+        raw.append(np.hstack([pts, rgb]))
+    np.savetxt(room / "office_3.txt", np.vstack(raw), fmt="%.6f %.6f %.6f %d %d %d")
+    cfg = {"raycast_engine": {"use_gpu": True}, "s3dis_data_root": str(tmp_path / "data"), "area": "Area_7",
+           "room": "office_3"}
+    sim = S3DISSimulator(cfg)
+    sim.raycast_engine = engine
+    sim.load_scene(mesh, "office_3")
+    scene = sim.run_simulation(line_trajectory((1.2, 1.5, 1.0), (2.8, 1.5, 1.0), 3))
+    assert all(f.semantic_labels is not None for f in scene.frames)        # the kernel's labels are attached ...
+    sim.save_results(scene, tmp_path / "out")
+    out = read_labeled_ply(tmp_path / "out" / "combined_pointcloud_with_label.ply")
+    loader = S3DISAnnotationLoader(str(tmp_path / "data"))
+    ap, al, ai = loader.create_labeled_pointcloud_with_instances(loader.load_room_annotations("Area_7", "office_3"))
+    rawd = np.loadtxt(room / "office_3.txt")
+    col = rawd[NearestNeighbors(n_neighbors=1, algorithm="ball_tree").fit(rawd[:, :3]).kneighbors(ap)[1][:, 0], 3:6] / 255.0
+    allp = scene.combined_points()
+    j = NearestNeighbors(n_neighbors=1, algorithm="ball_tree").fit(ap).kneighbors(allp)[1][:, 0]
+    assert len(out) == len(allp) > 500
+    assert np.array_equal(out["sem"], al[j].astype(np.uint16)) and np.array_equal(out["ins"], ai[j].astype(np.uint16))   # ... the files decide
+    assert np.array_equal(np.stack([out["red"], out["green"], out["blue"]], 1), (col[j] * 255).astype(np.uint8))
+    assert len(np.unique(out["red"])) > 50                                  # not the default grey

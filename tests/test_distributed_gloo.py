@@ -256,3 +256,151 @@ def test_triangle_id_gather_rebuilds_the_vstack_cloud(world):
     assert total > 100
     for rank, h, kk in got:
         assert kk == total and h == want, f"rank {rank} rebuilt a different cloud"
+
+
+class _StandInEngine:
+    """The three device steps of lidarcast.distributed.scan_frames_sharded played on the CPU by the oracle (the
+    product's RaycastEngineHIP runs them as HIP kernels; -m gpu tests compare the two).  Everything else -- pose
+    sharding, slab padding, the one all-gather, pose-major reassembly, the simulator's frames and statistics -- is
+    the product code under test."""
+
+    def __init__(self, mesh):
+        from oracle.c_oracle import OracleMesh
+        self.mesh = mesh
+        self.om = OracleMesh(mesh.vertices, mesh.triangles).build()
+        self.ctx = None
+
+    def scene_for(self, mesh):
+        return None
+
+    def _direction_table(self, k):
+        from lidar import IndoorLidar
+        return IndoorLidar.directions_from_vertical_degrees(k.vertical_degrees, k.horizontal_res)
+
+    def _scan(self, k, m):
+        from lidar import create_lidar
+        rays = create_lidar(k, m).get_rays()
+        t, prim = self.om.cast(rays)
+        d = rays[:, 3:] / np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+        pts = (rays[:, :3] + d * np.where(np.isfinite(t), t, 0)[:, None]).astype(np.float32)
+        keep = np.isfinite(t) & (np.linalg.norm(pts.astype(np.float64) - m[:3, 3], axis=1) < k.max_range)
+        return pts, prim, keep
+
+    def prim_gather(self, poses_local, rays_per_pose, dist_, group=None):
+        from lidarcast.distributed import PrimGather
+        return PrimGather(poses_local, rays_per_pose, dist_, torch.device("cpu"), group=group)
+
+    def scan_block_into(self, g, k, block, mesh):
+        n = g.rays_per_pose
+        g.slab.fill_(-1)
+        g.tile_count.zero_()
+        for j, m in enumerate(block.reshape(-1, 4, 4)):
+            _, prim, keep = self._scan(k, m)
+            g.prim[j * n:(j + 1) * n] = torch.from_numpy(np.where(keep, prim, 0xFFFFFFFF).astype(np.uint32).view(np.int32))
+            g.tile_count[j * (n // 64):(j + 1) * (n // 64)] = torch.from_numpy(keep.reshape(-1, 64).sum(1).astype(np.int32))
+
+    def cloud_from_gather(self, g, k, padded_poses, mesh):
+        rows, counts = [], []
+        per = g.per_rank()
+        for r, (prims, _) in enumerate(per):
+            for j in range(g.poses_local):
+                ids = prims[j].view(np.uint32)
+                sent = ids != 0xFFFFFFFF
+                counts.append(int(sent.sum()))
+                if not sent.any():
+                    continue
+                pts, prim, keep = self._scan(k, padded_poses[r * g.poses_local + j])
+                assert np.array_equal(ids[sent], prim[sent])        # the receiver recomputes the same hit
+                lab = (self.mesh.triangle_sem[ids[sent]].astype(np.uint32) |
+                       (self.mesh.triangle_ins[ids[sent]].astype(np.uint32) << 16)).view(np.float32)
+                rows.append(np.concatenate([pts[sent], lab[:, None]], 1))
+        rows = np.concatenate(rows).astype(np.float32) if rows else np.zeros((0, 4), np.float32)
+        return rows, np.array(counts, np.int64)
+
+    @staticmethod
+    def split_frames(frames, name):
+        ends = np.cumsum(frames["counts"])
+        return [frames[name][e - c:e] for c, e in zip(frames["counts"], ends)]
+
+
+def _simulator_worker(rank, world, port, q):
+    for p in (PKG, REPO, os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank,) + _simulate(distributed=True))
+    dist.destroy_process_group()
+
+
+def _simulate(distributed):
+    """S3DISSimulator.run_simulation over 7 yawed poses with the stand-in engine -> (sha of the scene, frame sizes,
+    first frame's range_mean).  Not bug-compatible mode, so the incident angles travel too."""
+    import s3dis_simulator
+    from helpers import sensor_small
+    from lidarcast import synth
+    from trajectory import Waypoint
+    mesh = synth.make_room(size=(3, 2.5, 2), num_boxes=2, seed=4, cell=0.1)
+    sim = s3dis_simulator.S3DISSimulator.__new__(s3dis_simulator.S3DISSimulator)
+    sim.config, sim.bug_compatible = {}, False
+    sim.lidar_config = sensor_small(lines=3, width=64, max_range=1.6)
+    sim.raycast_engine = _StandInEngine(mesh)
+    from containers import RoomBounds, S3DISScene
+    sim.scene = S3DISScene("room", mesh, RoomBounds.from_vertices(mesh.vertices))
+    wps = [Waypoint(0.6 + 0.3 * i, 1.2, 1.0, yaw=0.1 * i, timestamp=float(i)) for i in range(7)]
+    if distributed:
+        scene = sim.run_simulation(wps)                      # finds the initialised process group
+    else:                                                   # single process: the stand-in plays scan_frames itself
+        import lidarcast.distributed as ld
+
+        class _One:                                          # a world of one rank
+            @staticmethod
+            def get_world_size(g=None): return 1
+            @staticmethod
+            def get_rank(g=None): return 0
+            @staticmethod
+            def all_gather_into_tensor(out, inp, group=None, async_op=False): out.copy_(inp)
+        fr = ld.scan_frames_sharded(sim.raycast_engine, sim.lidar_config,
+                                    np.stack([w.to_pose_matrix() for w in wps]), mesh, _One)
+        return (hashlib.sha256(fr["point3"].tobytes() + fr["sem"].tobytes() + fr["ins"].tobytes()
+                               + fr["counts"].tobytes()).hexdigest(), fr["counts"].tolist(), None)
+    counts = np.array([len(f.points) for f in scene.frames], np.int64)
+    sem, ins = scene.combined_labels()
+    h = hashlib.sha256(scene.combined_points().tobytes() + sem.tobytes() + ins.tobytes() + counts.tobytes()).hexdigest()
+    ang = np.concatenate([f.incident_angles for f in scene.frames])
+    assert ang.dtype == np.float64 and len(ang) == counts.sum() and 0 <= ang.min() and ang.max() <= 90
+    return h, counts.tolist(), float(scene.frames[0].scan_quality.range_mean)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_aware_run_simulation(world):
+    """S3DISSimulator.run_simulation inside a gloo job of 2 and 3 ranks (ragged pose blocks 4+3 / 3+2+2): every rank
+    gets the frames of ALL poses, hash-identical to the single-process assembly, and builds the same statistics."""
+    from helpers import sensor_small
+    from lidar import create_lidar
+    from lidarcast import synth
+    from oracle import np_oracle
+    from oracle.c_oracle import OracleMesh
+    want, want_counts, _ = _simulate(distributed=False)
+    mesh = synth.make_room(size=(3, 2.5, 2), num_boxes=2, seed=4, cell=0.1)
+    om = OracleMesh(mesh.vertices, mesh.triangles).build()
+    k = sensor_small(lines=3, width=64, max_range=1.6)
+    from helpers import pose
+    frames = [np_oracle.lidar_intersect_mesh(om, create_lidar(k, pose(0.6 + 0.3 * i, 1.2, 1.0, 0.1 * i)))[0]
+              for i in range(7)]
+    assert want_counts == [len(f) for f in frames] and sum(want_counts) > 100      # = the reference's per-pose loop
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_simulator_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rm = np.linalg.norm(frames[0], axis=1).mean()
+    for rank, h, counts, range_mean in got:
+        assert counts == want_counts and h == want, f"rank {rank} assembled a different scene"
+        assert range_mean == rm

@@ -18,7 +18,7 @@ echo "stats done"
 cd $R
 tools/pmc.sh $TAG/pmc > /dev/null 2>&1
 cp gpurun_out/$TAG/pmc/summary.txt $OUT/pmc_summary.txt 2>/dev/null
-cp gpurun_out/$TAG/pmc/traffic.json $OUT/traffic.json 2>/dev/null
+cp gpurun_out/$TAG/pmc/pmc.json $OUT/pmc.json 2>/dev/null
 echo "pmc done"
 VW_LIST="1 2 4 8" tools/vw_sweep.sh > $OUT/vw_sweep.txt 2>&1
 cat $OUT/vw_sweep.txt

@@ -22,13 +22,18 @@ for k, cs in acc.items():
     for c, vs in sorted(cs.items()):
         print(f"  {c:34s} n={len(vs):3d} mean={sum(vs)/len(vs):.6g}")
 
-# traffic summary for bench.py (profiles/traffic_latest.json)
+# counter summary of the pose-batched trace kernel for bench.py (profiles/pmc_latest.json), stamped with the
+# fingerprint of the sources the profiled binary was built from: bench.py ignores it when the tree has moved on
 import json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as entry  # noqa: E402
 for k, cs in acc.items():
-    if "trace_kernel<true" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+    if "trace_kernel<1" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs and "SQ_INSTS_VALU" in cs:
         mean = lambda v: sum(v) / len(v)
-        out = {"kernel": k, "FETCH_SIZE_KB": mean(cs["FETCH_SIZE"]), "WRITE_SIZE_KB": mean(cs["WRITE_SIZE"]),
-               "rays_per_launch": 4194304, "command": "bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+        out = {"kernel": k, "source_sha256": entry.source_fingerprint(),
+               "FETCH_SIZE_KB": mean(cs["FETCH_SIZE"]), "WRITE_SIZE_KB": mean(cs["WRITE_SIZE"]),
+               "rays_per_launch": 4194304, "scene": os.environ.get("PMC_SCENE", "synth_A6_office2"),
+               "command": "bench.py " + os.environ.get("PMC_ARGS", "--steps 3 --warmup 1 --no-cpu-baseline"),
                "counters": {c: mean(v) for c, v in sorted(cs.items())}}
-        with open(os.path.join(root, "traffic.json"), "w") as f:
+        with open(os.path.join(root, "pmc.json"), "w") as f:
             json.dump(out, f, indent=1)

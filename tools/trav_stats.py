@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
-"""Per-ray traversal counters of the C3 workload (diagnostic build, LRC_STATS=1): how many inner-node
+"""Per-ray traversal counters of the C3 workload (instrumented kernel, lrc_debug_scan_stats): how many inner-node
 steps and triangle tests each ray takes, and how well the 64 lanes of a wave agree."""
 import os
 import sys
 
-os.environ["LRC_STATS"] = "1"
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import bench  # noqa: E402  (sets sys.path for the package)
@@ -13,17 +12,18 @@ import lidarcast  # noqa: E402
 from lidarcast import synth  # noqa: E402
 from lidar import IndoorLidar  # noqa: E402
 
-mesh = synth.make_scene(bench.SCENE)
+name = sys.argv[1] if len(sys.argv) > 1 else bench.SCENE
+mesh = synth.make_scene(name)
 ctx = lidarcast.Context(0)
 scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles)
 sensor = bench.c3_sensor()
-poses = bench.c3_poses(0, 1)[:8]
+Lx, Ly, _ = synth.SCENES[name]["size"]
+from trajectory import line_trajectory, poses_from_waypoints  # noqa: E402
+poses = poses_from_waypoints(line_trajectory((1.0, Ly / 2, 1.0), (Lx - 1.0, Ly / 2, 1.0), 64))[:8]
 dirs = IndoorLidar(intrinsics=sensor, pose=np.eye(4)).sensor_directions()
-out = scene.scan_poses(poses, dirs, sensor.max_range, want=("t", "normal3"))
-st = out["normal3"].reshape(-1, 64, 3)          # waves of 64 consecutive rays
-nodes, tris = st[..., 0], st[..., 1]
-uni = np.floor(st[..., 2])
-dead = np.round((st[..., 2] - uni) * 1024.0)
+st = scene.scan_stats(poses, dirs, sensor.max_range).reshape(-1, 64, 5).astype(np.float64)   # waves of 64 consecutive rays
+nodes, tris, uni, dead = st[..., 0], st[..., 1], st[..., 2], st[..., 3]
+print("scene", name, "pad-clause rejections", int(st[..., 4].sum()))
 print("rays", st.shape[0] * 64, "info", scene.info["max_depth"], scene.info["num_nodes"])
 for name, a in (("node steps", nodes), ("tri tests", tris)):
     print(f"{name:10s} per ray: mean {a.mean():6.2f}  p50 {np.median(a):5.1f}  p99 {np.percentile(a, 99):6.1f}  max {a.max():5.0f}"

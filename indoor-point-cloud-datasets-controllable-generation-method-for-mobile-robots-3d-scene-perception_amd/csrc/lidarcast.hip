@@ -87,6 +87,9 @@ struct lrc_ctx {
         uint64_t dirs_cap = 0;
     };
     TileScratch compact_scratch, cloud_scratch;
+    // *_compact entry points: kernels on one stream, the transfers of finished pose chunks on another
+    hipStream_t s_compute = nullptr, s_copy = nullptr;
+    hipEvent_t ev_chunk[8] = {};
 };
 
 struct lrc_scene {
@@ -248,6 +251,77 @@ __device__ __forceinline__ void rebuild_counts(const RebuildParams& q, uint32_t 
     }
 }
 
+// ---- fused write-back: everything after the closest hit is known (shared by the trace kernels) ------------------
+// best_slot = 0xFFFFFFFF: no hit.  FILTER: apply the max_range filter (scans and casts with a centre).
+template <bool FILTER_ALWAYS>
+__device__ __forceinline__ void write_back(const TraceParams& p, uint64_t gid, uint32_t tid, V3 o, V3 d, double cx,
+                                           double cy, double cz, float tbest, uint32_t best_slot) {
+    constexpr int GEN = FILTER_ALWAYS ? 1 : 0;
+    bool keep = best_slot != 0xFFFFFFFFu;
+    float t_out = __builtin_inff();
+    uint32_t prim = LRC_INVALID_PRIM;
+    float nx = 0.f, ny = 0.f, nz = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+    uint32_t label = 0;
+    double inc = 0.0;
+    float inten = 0.f;
+    if (keep && p.range_noise) {
+        // opt-in range noise (the reference declares range_noise_std but never applies it, lidar_intrinsics.py:
+        // 364-389 has no caller): host-drawn additive noise on the range; a non-positive range drops the return
+        tbest = tbest + p.range_noise[gid];
+        keep = tbest > 0.0f;
+    }
+    if (keep) {
+        // p = o + (d/|d|)*t : numpy float32, one rounding per operation (raycast_engine_cpu.py:57-62)
+        V3 hh, pp;
+        hit_point(o, d, tbest, hh, pp);
+        const float hx = hh.x, hy = hh.y, hz = hh.z;
+        px = pp.x; py = pp.y; pz = pp.z;
+        // range filter + incident angle in float64 (raycast_engine_cpu.py:95-107)
+        const double ex = (double)px - cx, ey = (double)py - cy, ez = (double)pz - cz;
+        const double dist = __builtin_sqrt((ex * ex + ey * ey) + ez * ez);
+        if (p.has_center || GEN != 0) keep = dist < p.max_range;
+        if (p.min_range > 0.0) keep = keep & (dist >= p.min_range);     // opt-in; the reference never applies it
+        if (keep) {
+            t_out = tbest;
+            prim = p.slot_prim[best_slot];
+            label = p.slot_label[best_slot];
+            if (p.out.normal3 || p.out.intensity || (p.out.incident_deg && p.incident_mode == 1)) {
+                const float4 c = p.tris[(size_t)best_slot * 3 + 2];
+                const float len = __builtin_sqrtf(fma_(c.w, c.w, fma_(c.z, c.z, c.y * c.y)));
+                nx = c.y / len; ny = c.z / len; nz = c.w / len;
+            }
+            if (p.out.incident_deg) {
+                if (p.incident_mode == 1) {   // opt-in: angle between the ray and the surface normal
+                    const double cs = __builtin_fabs(((double)hx * (double)nx + (double)hy * (double)ny) +
+                                                     (double)hz * (double)nz);
+                    inc = acos(cs < 1.0 ? cs : 1.0) * kRadToDeg;
+                } else {
+                    inc = acos(__builtin_fabs(ez / dist)) * kRadToDeg;
+                }
+            }
+            if (p.out.intensity)      // opt-in: Lambertian return |h.n|, float32 (same FMA order as every dot product here)
+                inten = __builtin_fabsf(fma_(hz, nz, fma_(hy, ny, hx * nx)));
+            if (!p.out.normal3) { nx = ny = nz = 0.f; }
+        } else {
+            px = py = pz = 0.f;
+        }
+    }
+    if (p.out.tile_count) {   // kept rays of this wave's 64 consecutive outputs (feeds lrc_compact_dev)
+        const unsigned long long m = __ballot(keep);
+        if ((tid & 63u) == 0) p.out.tile_count[gid >> 6] = (uint32_t)__popcll(m);
+    }
+    if (p.out.t) p.out.t[gid] = t_out;
+    if (p.out.t_label) ((uint2*)p.out.t_label)[gid] = make_uint2(__float_as_uint(t_out), label);
+    if (p.out.prim) p.out.prim[gid] = prim;
+    if (p.out.normal3) { float* q = p.out.normal3 + gid * 3; q[0] = nx; q[1] = ny; q[2] = nz; }
+    if (p.out.point3) { float* q = p.out.point3 + gid * 3; q[0] = px; q[1] = py; q[2] = pz; }
+    if (p.out.sem) p.out.sem[gid] = (uint16_t)(label & 0xFFFFu);
+    if (p.out.ins) p.out.ins[gid] = (uint16_t)(label >> 16);
+    if (p.out.incident_deg) p.out.incident_deg[gid] = inc;
+    if (p.out.intensity) p.out.intensity[gid] = inten;
+
+}
+
 constexpr int kStatsWords = 5;   // node steps, triangle tests, wave-uniform node steps, dead node steps, pad-clause rejections
 
 // GEN: 0 = explicit rays, 1 = pose x direction table, 2 = pose x per-ray scan angles (dual-axis sensor, opt-in)
@@ -401,75 +475,153 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
     }
 
     // ---- fused write-back ----
-    bool keep = best_slot != 0xFFFFFFFFu;
-    float t_out = __builtin_inff();
-    uint32_t prim = LRC_INVALID_PRIM;
-    float nx = 0.f, ny = 0.f, nz = 0.f, px = 0.f, py = 0.f, pz = 0.f;
-    uint32_t label = 0;
-    double inc = 0.0;
-    float inten = 0.f;
-    if (keep && p.range_noise) {
-        // opt-in range noise (the reference declares range_noise_std but never applies it, lidar_intrinsics.py:
-        // 364-389 has no caller): host-drawn additive noise on the range; a non-positive range drops the return
-        tbest = tbest + p.range_noise[gid];
-        keep = tbest > 0.0f;
-    }
-    if (keep) {
-        // p = o + (d/|d|)*t : numpy float32, one rounding per operation (raycast_engine_cpu.py:57-62)
-        V3 hh, pp;
-        hit_point(o, d, tbest, hh, pp);
-        const float hx = hh.x, hy = hh.y, hz = hh.z;
-        px = pp.x; py = pp.y; pz = pp.z;
-        // range filter + incident angle in float64 (raycast_engine_cpu.py:95-107)
-        const double ex = (double)px - cx, ey = (double)py - cy, ez = (double)pz - cz;
-        const double dist = __builtin_sqrt((ex * ex + ey * ey) + ez * ez);
-        if (p.has_center || GEN != 0) keep = dist < p.max_range;
-        if (p.min_range > 0.0) keep = keep & (dist >= p.min_range);     // opt-in; the reference never applies it
-        if (keep) {
-            t_out = tbest;
-            prim = p.slot_prim[best_slot];
-            label = p.slot_label[best_slot];
-            if (p.out.normal3 || p.out.intensity || (p.out.incident_deg && p.incident_mode == 1)) {
-                const float4 c = p.tris[(size_t)best_slot * 3 + 2];
-                const float len = __builtin_sqrtf(fma_(c.w, c.w, fma_(c.z, c.z, c.y * c.y)));
-                nx = c.y / len; ny = c.z / len; nz = c.w / len;
-            }
-            if (p.out.incident_deg) {
-                if (p.incident_mode == 1) {   // opt-in: angle between the ray and the surface normal
-                    const double cs = __builtin_fabs(((double)hx * (double)nx + (double)hy * (double)ny) +
-                                                     (double)hz * (double)nz);
-                    inc = acos(cs < 1.0 ? cs : 1.0) * kRadToDeg;
-                } else {
-                    inc = acos(__builtin_fabs(ez / dist)) * kRadToDeg;
-                }
-            }
-            if (p.out.intensity)      // opt-in: Lambertian return |h.n|, float32 (same FMA order as every dot product here)
-                inten = __builtin_fabsf(fma_(hz, nz, fma_(hy, ny, hx * nx)));
-            if (!p.out.normal3) { nx = ny = nz = 0.f; }
-        } else {
-            px = py = pz = 0.f;
-        }
-    }
-    if (p.out.tile_count) {   // kept rays of this wave's 64 consecutive outputs (feeds lrc_compact_dev)
-        const unsigned long long m = __ballot(keep);
-        if ((tid & 63u) == 0) p.out.tile_count[gid >> 6] = (uint32_t)__popcll(m);
-    }
-    if (p.out.t) p.out.t[gid] = t_out;
-    if (p.out.t_label) ((uint2*)p.out.t_label)[gid] = make_uint2(__float_as_uint(t_out), label);
-    if (p.out.prim) p.out.prim[gid] = prim;
+    write_back<GEN != 0>(p, gid, tid, o, d, cx, cy, cz, tbest, best_slot);
     if (STATS) {
         if (p.stats) {
             uint32_t* q = p.stats + gid * kStatsWords;
             q[0] = st_nodes; q[1] = st_tris; q[2] = st_uni; q[3] = st_dead; q[4] = st_pad;
         }
     }
-    if (p.out.normal3) { float* q = p.out.normal3 + gid * 3; q[0] = nx; q[1] = ny; q[2] = nz; }
-    if (p.out.point3) { float* q = p.out.point3 + gid * 3; q[0] = px; q[1] = py; q[2] = pz; }
-    if (p.out.sem) p.out.sem[gid] = (uint16_t)(label & 0xFFFFu);
-    if (p.out.ins) p.out.ins[gid] = (uint16_t)(label >> 16);
-    if (p.out.incident_deg) p.out.incident_deg[gid] = inc;
-    if (p.out.intensity) p.out.intensity[gid] = inten;
 
+}
+
+// ---- measured alternative: K rays per lane with private refill (LRC_REFILL=K) -------------
+// One wave owns K consecutive 64-ray tiles of a pose-batched scan; lane l traces rays l, 64+l, 128+l, ... one after the
+// other, starting its next ray the moment the current one is done instead of idling until the slowest lane of the wave
+// has finished ("private refill").  The closest hit (t, slot) of each ray is parked in LDS and the whole write-back
+// runs afterwards, coherently, K passes of 64 lanes.  The next ray's direction is fetched while the current one is
+// traced.  Same arithmetic, same result bytes as trace_kernel (tests/test_parity_gpu.py::
+// test_kernel_variants_are_bit_identical); what changes is the balance of work inside a wave (tools/trav_stats.py:
+// 0.68 -> 0.77 / 0.84 for K = 2 / 4) at the price of (a) refilled lanes restarting at the root while their
+// neighbours are deep in the tree, which takes the wave off the scalar-fetch path, (b) K x 512 B more LDS per wave and
+// 6 more VGPRs, i.e. fewer resident waves.
+// W = resident waves per SIMD the register allocator must leave room for (its natural footprint is 78 / 93 VGPRs for
+// K = 2 / 4, i.e. 6 / 5 waves; 7 waves cost a few spilled registers)
+template <int K, int W>
+__global__ __launch_bounds__(kTBlock, W) void trace_refill_kernel(const TraceParams p, uint32_t depth) {
+    extern __shared__ int s_mem[];                 // [depth][64] stacks | [K][64] {t bits, slot}
+    int* s_stack = s_mem;
+    uint2* s_res = (uint2*)(s_mem + (size_t)depth * 64);
+    const uint32_t tid = threadIdx.x;
+    // the host launches this kernel only when rays_per_pose % (64 K) == 0: a wave's K tiles lie in ONE pose, so the pose
+    // and everything derived from it is wave-uniform (scalar loads, SGPR operands)
+    const uint64_t N = p.rays_per_pose;
+    const uint64_t tile0 = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * (64u * K);
+    if (tile0 >= p.total) return;
+    const uint64_t pose = tile0 / N;
+    const uint32_t i0 = (uint32_t)(tile0 - pose * N);
+    const double* M = p.poses16 + pose * 16;
+    const uint64_t base = tile0 + tid;
+
+    V3 o, d;
+    RaySlab sl;
+    float tbest;
+    uint32_t best_slot, best_prim;
+    int sp = 0, ref = ~0;
+    int k = 0;
+    double nd0 = 0.0, nd1 = 0.0, nd2 = 0.0;        // next ray's sensor-frame direction, in flight
+
+    auto fetch_next = [&](int kk) {
+        if (kk < K) {
+            const double* dv = p.dirs3 + (size_t)(i0 + (uint32_t)kk * 64u + tid) * 3;
+            nd0 = dv[0]; nd1 = dv[1]; nd2 = dv[2];
+        }
+    };
+    // ray kk from the prefetched direction; false when the lane has no ray kk
+    auto begin = [&](int kk) -> bool {
+        if (kk >= K) return false;
+        d.x = (float)dgemm_row(nd0, nd1, nd2, M[0], M[1], M[2]);
+        d.y = (float)dgemm_row(nd0, nd1, nd2, M[4], M[5], M[6]);
+        d.z = (float)dgemm_row(nd0, nd1, nd2, M[8], M[9], M[10]);
+        o.x = (float)M[3]; o.y = (float)M[7]; o.z = (float)M[11];
+        sl = make_slab(o, d);
+        tbest = __builtin_inff();
+        best_slot = 0xFFFFFFFFu; best_prim = 0xFFFFFFFFu;
+        sp = 0;
+        ref = (p.num_nodes && finite_ray(o, d)) ? 0 : ~0;
+        return true;
+    };
+    fetch_next(0);
+    begin(0);
+    fetch_next(1);
+
+    auto step = [&](const F4 q0, const F4 q1, const F4 q2, const F4 q3) {
+        float n0, f0, n1, f1;
+        slab_interval(sl, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, n0, f0);
+        slab_interval(sl, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, n1, f1);
+        const bool h0 = (n0 <= f0) & (n0 <= tbest);
+        const bool h1 = (n1 <= f1) & (n1 <= tbest);
+        const int r0 = __float_as_int(q3.x), r1 = __float_as_int(q3.y);
+        if (h0 & h1) {
+            const bool first0 = n0 <= n1;
+            s_stack[sp * 64 + tid] = first0 ? r1 : r0;
+            ++sp;
+            ref = first0 ? r0 : r1;
+        } else if (h0) {
+            ref = r0;
+        } else if (h1) {
+            ref = r1;
+        } else if (sp == 0) {
+            ref = ~0;
+        } else {
+            --sp;
+            ref = s_stack[sp * 64 + tid];
+        }
+    };
+    auto leaf = [&](const int lref) {
+        const uint32_t enc = (uint32_t)(~lref);
+        const uint32_t first = enc >> 3, cnt = enc & 7u;
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t slot = first + j;
+            const float4* tr = p.tris + (size_t)slot * 3;
+            const float4 a = tr[0], b = tr[1], c = tr[2];
+            const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
+            float t;
+            if (tri_hit(o, d, sl, v0, v1, v2, ng, t)) {
+                if (t < tbest) {
+                    tbest = t; best_slot = slot; best_prim = 0xFFFFFFFFu;
+                } else if (t == tbest) {
+                    if (best_prim == 0xFFFFFFFFu) best_prim = p.slot_prim[best_slot];
+                    const uint32_t pr = p.slot_prim[slot];
+                    if (pr < best_prim) { best_slot = slot; best_prim = pr; }
+                }
+            }
+        }
+    };
+
+    while (true) {
+        while (ref >= 0) {
+            const int uref = __builtin_amdgcn_readfirstlane(ref);
+            if (__builtin_amdgcn_ballot_w64(ref != uref) == 0ull) {
+                const float4* n = p.nodes + (size_t)uref * 4;
+                step(ld_uniform(n), ld_uniform(n + 1), ld_uniform(n + 2), ld_uniform(n + 3));
+            } else {
+                const F4* n = (const F4*)(p.nodes + (size_t)ref * 4);
+                step(n[0], n[1], n[2], n[3]);
+            }
+        }
+        leaf(ref);
+        if (sp != 0) {
+            --sp;
+            ref = s_stack[sp * 64 + tid];
+            continue;
+        }
+        // this lane's ray is done: park its hit, start the next one
+        s_res[k * 64 + tid] = make_uint2(__float_as_uint(tbest), best_slot);
+        ++k;
+        if (!begin(k)) break;
+        fetch_next(k + 1);
+    }
+
+    // ---- coherent write-back, one pass per tile ----
+#pragma unroll 1
+    for (int kk = 0; kk < K; ++kk) {
+        const uint64_t gid = base + (uint64_t)kk * 64u;
+        double cx, cy, cz;
+        gen_ray(p.poses16, p.dirs3, pose, i0 + (uint32_t)kk * 64u + tid, o, d, cx, cy, cz);
+        const uint2 r = s_res[kk * 64 + tid];
+        write_back<true>(p, gid, tid, o, d, cx, cy, cz, __uint_as_float(r.x), r.y);
+    }
 }
 
 // ---- compaction -------------------------------------------------------------------------------
@@ -733,6 +885,9 @@ int lrc_ctx_destroy(lrc_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (int k = 0; k < kPoolSlots; ++k)
         if (ctx->pool[k]) (void)hipFree(ctx->pool[k]);
+    if (ctx->s_compute) (void)hipStreamDestroy(ctx->s_compute);
+    if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
+    for (hipEvent_t e : ctx->ev_chunk) if (e) (void)hipEventDestroy(e);
     for (lrc_ctx::TileScratch* sc : {&ctx->compact_scratch, &ctx->cloud_scratch}) {
         if (sc->d_tile_off) (void)hipFree(sc->d_tile_off);
         if (sc->d_tile_cnt) (void)hipFree(sc->d_tile_cnt);
@@ -911,6 +1066,22 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
         else if (uni) { if (leafw == 2) LRC_LAUNCH(G, 2, true, false); else LRC_LAUNCH(G, 1, true, false); }  \
         else { if (leafw == 2) LRC_LAUNCH(G, 2, false, false); else LRC_LAUNCH(G, 1, false, false); }         \
     } while (0)
+    static const int refill = [] { const char* e = std::getenv("LRC_REFILL"); return e ? std::atoi(e) : 0; }();
+    if (refill > 1 && gen == 1 && !stats && p.rays_per_pose % (64u * (refill >= 4 ? 4 : 2)) == 0) {
+        // measured alternative: K rays per lane with private refill
+        const int K = refill >= 4 ? 4 : 2;
+        const uint64_t nb = (p.total + 64ull * K - 1) / (64ull * K);
+        const size_t ldsK = ((size_t)depth * 64 + (size_t)K * 64 * 2) * sizeof(int);
+        static const int rw = [] { const char* e = std::getenv("LRC_REFILL_W"); return e ? std::atoi(e) : 0; }();
+#define LRC_RF(KK, WW) hipLaunchKernelGGL((trace_refill_kernel<KK, WW>), dim3((uint32_t)nb), dim3(kTBlock), ldsK, st, p, depth)
+        if (K == 4) { if (rw >= 7) LRC_RF(4, 7); else LRC_RF(4, 5); }
+        else { if (rw >= 7) LRC_RF(2, 7); else LRC_RF(2, 6); }
+#undef LRC_RF
+        LRC_HIP(hipGetLastError());
+        s->launches += 1;
+        s->rays += p.total;
+        return LRC_OK;
+    }
     if (stats) {   // diagnostic build: per-ray traversal counters (lrc_debug_scan_stats)
         if (gen == 1) hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
         else if (gen == 0) hipLaunchKernelGGL((trace_kernel<0, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
@@ -1393,33 +1564,96 @@ struct FrameStage {
     }
 };
 
-// trace (already described by p, outputs wired to st.rec) -> compaction -> counts to the host -> ONE bulk transfer per
-// requested array of exactly the kept rows.  Pinned destinations (lrc_host_alloc) make the transfers true DMA.
+int ensure_streams(lrc_ctx* ctx) {
+    if (!ctx->s_compute) LRC_HIP(hipStreamCreateWithFlags(&ctx->s_compute, hipStreamNonBlocking));
+    if (!ctx->s_copy) LRC_HIP(hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
+    for (hipEvent_t& e : ctx->ev_chunk)
+        if (!e) LRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return LRC_OK;
+}
+
+// Trace -> compaction -> kept rows to the host, pipelined over contiguous chunks of poses: while chunk c's rows cross
+// PCIe on the copy stream, chunk c+1 is traced and compacted on the compute stream.  Each chunk compacts into its own
+// worst-case region of the device arrays (rows [p0*N, ...)); the host destination offset is the running row count, so
+// the host arrays come out packed in pose order (np.vstack order) without a second pass.  Pinned destinations
+// (lrc_host_alloc) make the transfers true DMA.  `p` describes the whole scan (inputs already in HBM).
 int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_t P, uint64_t N, const lrc_frames* out,
                   uint64_t capacity, uint64_t* out_total) {
-    p.out = st.rec;
-    int rc = launch_trace(s, p, gen, nullptr);
+    lrc_ctx* ctx = s->ctx;
+    int rc = ensure_streams(ctx);
     if (rc) return rc;
-    if ((rc = lrc_compact_dev(s->ctx, P, N, &st.io, nullptr))) return rc;
-    LRC_HIP(hipMemcpyAsync(out->counts, st.io.counts, P * 8, hipMemcpyDeviceToHost, nullptr));
+    // chunks only pay when there is enough to overlap, and need pose boundaries on 64-ray tiles (fused keep counts)
+    uint64_t chunks = (P * N >= (1u << 20) && N % 64 == 0) ? (P < 4 ? P : 4) : 1;
+    const float* noise = p.range_noise ? p.range_noise : s->opts.range_noise;   // staged in HBM by NoiseStage
+    // inputs were enqueued on the null stream by the caller: make them visible to the compute stream
     LRC_HIP(hipStreamSynchronize(nullptr));
+    uint64_t p0 = 0;
+    for (uint64_t c = 0; c < chunks; ++c) {
+        const uint64_t p1 = P * (c + 1) / chunks, np_ = p1 - p0, r0 = p0 * N;
+        TraceParams q = p;
+        q.poses16 = p.poses16 + p0 * 16;
+        if (q.angles2) q.angles2 = p.angles2 + r0 * 2;
+        if (q.keep_mask) q.keep_mask = p.keep_mask + r0;
+        q.total = np_ * N;
+        q.range_noise = nullptr;
+        lrc_scan_options saved = s->opts;
+        if (noise) { s->opts.range_noise = noise + r0; s->opts.range_noise_len = q.total; }
+        q.out = st.rec;
+        q.out.t = st.rec.t + r0;
+        if (q.out.point3) q.out.point3 = st.rec.point3 + r0 * 3;
+        if (q.out.sem) q.out.sem = st.rec.sem + r0;
+        if (q.out.ins) q.out.ins = st.rec.ins + r0;
+        if (q.out.incident_deg) q.out.incident_deg = st.rec.incident_deg + r0;
+        q.out.tile_count = st.rec.tile_count + (r0 + 63) / 64;
+        rc = launch_trace(s, q, gen, ctx->s_compute);
+        s->opts = saved;
+        if (rc) return rc;
+        lrc_compact_io io = st.io;
+        io.t = q.out.t; io.point3 = q.out.point3; io.sem = q.out.sem; io.ins = q.out.ins;
+        io.incident_deg = q.out.incident_deg; io.tile_count = q.out.tile_count;
+        io.counts = st.io.counts + p0;
+        if (io.out_point3) io.out_point3 = st.io.out_point3 + r0 * 3;
+        if (io.out_sem) io.out_sem = st.io.out_sem + r0;
+        if (io.out_ins) io.out_ins = st.io.out_ins + r0;
+        if (io.out_incident_deg) io.out_incident_deg = st.io.out_incident_deg + r0;
+        if (io.out_index) io.out_index = st.io.out_index + r0;
+        if (io.out_xyzl) io.out_xyzl = st.io.out_xyzl + r0 * 4;
+        if (io.out_range_origin) io.out_range_origin = st.io.out_range_origin + r0;
+        if ((rc = lrc_compact_dev(ctx, np_, N, &io, ctx->s_compute))) return rc;
+        LRC_HIP(hipMemcpyAsync(out->counts + p0, st.io.counts + p0, np_ * 8, hipMemcpyDeviceToHost, ctx->s_compute));
+        LRC_HIP(hipEventRecord(ctx->ev_chunk[c], ctx->s_compute));
+        p0 = p1;
+    }
     uint64_t K = 0;
-    for (uint64_t k = 0; k < P; ++k) K += out->counts[k];
+    int status = LRC_OK;
+    p0 = 0;
+    for (uint64_t c = 0; c < chunks; ++c) {
+        const uint64_t p1 = P * (c + 1) / chunks, r0 = p0 * N;
+        LRC_HIP(hipEventSynchronize(ctx->ev_chunk[c]));
+        uint64_t Kc = 0;
+        for (uint64_t k = p0; k < p1; ++k) Kc += out->counts[k];
+        if (K + Kc > capacity) status = LRC_ERR_INVALID_ARG;        // keep counting: the caller learns the size needed
+        if (status == LRC_OK && Kc) {
+            hipStream_t cs = ctx->s_copy;
+            if (out->point3) LRC_HIP(hipMemcpyAsync(out->point3 + K * 3, st.io.out_point3 + r0 * 3, Kc * 12, hipMemcpyDeviceToHost, cs));
+            if (out->sem) LRC_HIP(hipMemcpyAsync(out->sem + K, st.io.out_sem + r0, Kc * 2, hipMemcpyDeviceToHost, cs));
+            if (out->ins) LRC_HIP(hipMemcpyAsync(out->ins + K, st.io.out_ins + r0, Kc * 2, hipMemcpyDeviceToHost, cs));
+            if (out->incident_deg)
+                LRC_HIP(hipMemcpyAsync(out->incident_deg + K, st.io.out_incident_deg + r0, Kc * 8, hipMemcpyDeviceToHost, cs));
+            if (out->index) LRC_HIP(hipMemcpyAsync(out->index + K, st.io.out_index + r0, Kc * 4, hipMemcpyDeviceToHost, cs));
+            if (out->xyzl) LRC_HIP(hipMemcpyAsync(out->xyzl + K * 4, st.io.out_xyzl + r0 * 4, Kc * 16, hipMemcpyDeviceToHost, cs));
+            if (out->range_origin)
+                LRC_HIP(hipMemcpyAsync(out->range_origin + K, st.io.out_range_origin + r0, Kc * 4, hipMemcpyDeviceToHost, cs));
+        }
+        K += Kc;
+        p0 = p1;
+    }
+    LRC_HIP(hipStreamSynchronize(ctx->s_copy));
+    LRC_HIP(hipStreamSynchronize(ctx->s_compute));
     if (out_total) *out_total = K;
-    if (K > capacity)
-        return fail(LRC_ERR_INVALID_ARG, "frame buffers too small: capacity " + std::to_string(capacity) + " rows, the scan kept " +
-                                             std::to_string(K));
-    if (!K) return LRC_OK;
-    if (out->point3) LRC_HIP(hipMemcpyAsync(out->point3, st.io.out_point3, K * 12, hipMemcpyDeviceToHost, nullptr));
-    if (out->sem) LRC_HIP(hipMemcpyAsync(out->sem, st.io.out_sem, K * 2, hipMemcpyDeviceToHost, nullptr));
-    if (out->ins) LRC_HIP(hipMemcpyAsync(out->ins, st.io.out_ins, K * 2, hipMemcpyDeviceToHost, nullptr));
-    if (out->incident_deg)
-        LRC_HIP(hipMemcpyAsync(out->incident_deg, st.io.out_incident_deg, K * 8, hipMemcpyDeviceToHost, nullptr));
-    if (out->index) LRC_HIP(hipMemcpyAsync(out->index, st.io.out_index, K * 4, hipMemcpyDeviceToHost, nullptr));
-    if (out->xyzl) LRC_HIP(hipMemcpyAsync(out->xyzl, st.io.out_xyzl, K * 16, hipMemcpyDeviceToHost, nullptr));
-    if (out->range_origin)
-        LRC_HIP(hipMemcpyAsync(out->range_origin, st.io.out_range_origin, K * 4, hipMemcpyDeviceToHost, nullptr));
-    LRC_HIP(hipStreamSynchronize(nullptr));
+    if (status != LRC_OK)
+        return fail(LRC_ERR_INVALID_ARG, "frame buffers too small: capacity " + std::to_string(capacity) +
+                                             " rows, the scan kept " + std::to_string(K));
     return LRC_OK;
 }
 }  // namespace

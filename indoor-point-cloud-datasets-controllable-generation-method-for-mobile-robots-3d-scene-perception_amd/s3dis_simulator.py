@@ -24,6 +24,7 @@ from raycast_engine import RaycastEngineCPU, RaycastEngineGPU
 from trajectory import AutoTrajectoryGenerator, PathType, SmartTrajectoryGenerator, Waypoint, poses_from_waypoints
 
 
+_POOL = None             # thread pool of _quality_many, created on first use
 _NO_GROUP = object()     # run_simulation(process_group=_NO_GROUP): single-process scan even inside a distributed job
 
 
@@ -147,6 +148,30 @@ class S3DISSimulator:
             scan_density=k / room_volume,
             range_mean=np.mean(ranges) if k > 0 else 0, range_std=np.std(ranges) if k > 0 else 0)
 
+    def _quality_many(self, points, angles, total_points_per_scan, room_volume, ranges):
+        """ScanQuality of every frame; frames are independent, so a small thread pool reduces them side by side."""
+        zero_angles = self.bug_compatible      # mean and std of an all-zero block are exactly 0.0: no need to reduce it
+
+        def one(i):
+            k = len(points[i])
+            r = ranges[i]
+            a = angles[i]
+            return ScanQuality(
+                coverage_ratio=k / total_points_per_scan, num_points=k,
+                incident_angle_mean=(np.float64(0.0) if zero_angles else np.mean(a)) if k > 0 else 0,
+                incident_angle_std=(np.float64(0.0) if zero_angles else np.std(a)) if k > 0 else 0,
+                scan_density=k / room_volume,
+                range_mean=np.mean(r) if k > 0 else 0, range_std=np.std(r) if k > 0 else 0)
+        n = len(points)
+        if n < 8 or sum(len(p) for p in points) < (1 << 18):
+            return [one(i) for i in range(n)]
+        global _POOL
+        if _POOL is None:
+            import os
+            from concurrent.futures import ThreadPoolExecutor
+            _POOL = ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 2))))
+        return list(_POOL.map(one, range(n)))
+
     def run_simulation(self, waypoints: List[Waypoint], process_group=None) -> S3DISSimScene:
         """The scan stage (reference :220-296).  Inside an initialised ``torch.distributed`` job with more than one
         rank (one process per GPU, backend "nccl" = RCCL), or with an explicit ``process_group``, the waypoints are
@@ -204,20 +229,24 @@ class S3DISSimulator:
         if fr is not None:
             pts_f, sem_f, ins_f = (engine.split_frames(fr, a) for a in ("point3", "sem", "ins"))
             rng_f = engine.split_frames(fr, "range_origin")
-            ang_f = None if self.bug_compatible else engine.split_frames(fr, "incident_deg")
+            if self.bug_compatible:            # one zero block, frames take views of it (reference :266-269)
+                fr["incident_deg"] = np.zeros(fr["total"])
+            ang_f = engine.split_frames(fr, "incident_deg")
+            # per-frame statistics are numpy reductions over 10^4..10^5 values each; they release the GIL, so the
+            # frames of a long trajectory are reduced side by side (same numpy calls, same values)
+            qual = self._quality_many(pts_f, ang_f, total, volume, rng_f)
         for i, wp in enumerate(waypoints):
             if fr is not None:
-                points, sem, ins, ranges = pts_f[i], sem_f[i], ins_f[i], rng_f[i]
-                angles = np.zeros(len(points)) if self.bug_compatible else ang_f[i]
-            else:
-                a, b = off[i], off[i + 1]
-                keep = seg["t"][a:b] != np.inf
-                points, angles = seg["point3"][a:b][keep], seg["incident_deg"][a:b][keep]
-                sem, ins = seg["sem"][a:b][keep], seg["ins"][a:b][keep]
-                ranges = None
-                if self.bug_compatible:
-                    angles = np.zeros(len(points))            # reference :266-269
-            q = self._quality(points, angles, total, volume, ranges)
+                sim_scene.append_frame(S3DISSimFrame(i, pts_f[i], ang_f[i], qual[i], semantic_labels=sem_f[i],
+                                                     instance_labels=ins_f[i]))
+                continue
+            a, b = off[i], off[i + 1]
+            keep = seg["t"][a:b] != np.inf
+            points, angles = seg["point3"][a:b][keep], seg["incident_deg"][a:b][keep]
+            sem, ins = seg["sem"][a:b][keep], seg["ins"][a:b][keep]
+            if self.bug_compatible:
+                angles = np.zeros(len(points))                # reference :266-269
+            q = self._quality(points, angles, total, volume)
             sim_scene.append_frame(S3DISSimFrame(i, points, angles, q, semantic_labels=sem,
                                                  instance_labels=ins))
         sim_scene.compute_statistics(time.time() - start)

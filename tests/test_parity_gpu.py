@@ -961,7 +961,8 @@ def test_kernel_variants_are_bit_identical():
     digests = {}
     for name, env in {"default": {}, "no_scalar_fetch": {"LRC_UNIFORM": "0"}, "leaf_pairs": {"LRC_LEAFW": "2"},
                       "speculative": {"LRC_SPEC": "1"}, "leaves_of_2": {"LRC_MAX_LEAF": "2"},
-                      "leaves_of_1": {"LRC_MAX_LEAF": "1"}}.items():
+                      "leaves_of_1": {"LRC_MAX_LEAF": "1"}, "refill_2": {"LRC_REFILL": "2"},
+                      "refill_4": {"LRC_REFILL": "4"}, "refill_2_w7": {"LRC_REFILL": "2", "LRC_REFILL_W": "7"}}.items():
         e = dict(os.environ)
         e.update(env)
         r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=300, env=e, check=True)

@@ -1,0 +1,9 @@
+#!/bin/bash
+# tools/refill_sweep.sh -- the pose-batched trace kernel on the C3 workload: default (one ray per lane) against the
+# private-refill variants (K rays per lane; W = waves per SIMD the register allocator leaves room for).  GPU box only.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd $R
+for cfg in "" "LRC_REFILL=2" "LRC_REFILL=2 LRC_REFILL_W=7" "LRC_REFILL=4" "LRC_REFILL=4 LRC_REFILL_W=7"; do
+  echo "== ${cfg:-default}"
+  env $cfg timeout -k 10 120 python3 tools/trace_time.py "$@" 2>&1 | tail -1
+done

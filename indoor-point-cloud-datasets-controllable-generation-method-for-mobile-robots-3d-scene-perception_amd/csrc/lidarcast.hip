@@ -90,6 +90,8 @@ struct lrc_ctx {
     // *_compact entry points: kernels on one stream, the transfers of finished pose chunks on another
     hipStream_t s_compute = nullptr, s_copy = nullptr;
     hipEvent_t ev_chunk[8] = {};
+    uint64_t* h_counts = nullptr;       // page-locked landing area of the per-pose counts (async copies need one)
+    uint64_t h_counts_cap = 0;
 };
 
 struct lrc_scene {
@@ -885,6 +887,7 @@ int lrc_ctx_destroy(lrc_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (int k = 0; k < kPoolSlots; ++k)
         if (ctx->pool[k]) (void)hipFree(ctx->pool[k]);
+    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->s_compute) (void)hipStreamDestroy(ctx->s_compute);
     if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
     for (hipEvent_t e : ctx->ev_chunk) if (e) (void)hipEventDestroy(e);
@@ -1582,6 +1585,11 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
     lrc_ctx* ctx = s->ctx;
     int rc = ensure_streams(ctx);
     if (rc) return rc;
+    if (ctx->h_counts_cap < P) {
+        if (ctx->h_counts) { (void)hipHostFree(ctx->h_counts); ctx->h_counts = nullptr; ctx->h_counts_cap = 0; }
+        LRC_HIP(hipHostMalloc((void**)&ctx->h_counts, (P + P / 4 + 64) * 8, hipHostMallocDefault));
+        ctx->h_counts_cap = P + P / 4 + 64;
+    }
     // chunks only pay when there is enough to overlap, and need pose boundaries on 64-ray tiles (fused keep counts)
     uint64_t chunks = (P * N >= (1u << 20) && N % 64 == 0) ? (P < 4 ? P : 4) : 1;
     const float* noise = p.range_noise ? p.range_noise : s->opts.range_noise;   // staged in HBM by NoiseStage
@@ -1620,7 +1628,7 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
         if (io.out_xyzl) io.out_xyzl = st.io.out_xyzl + r0 * 4;
         if (io.out_range_origin) io.out_range_origin = st.io.out_range_origin + r0;
         if ((rc = lrc_compact_dev(ctx, np_, N, &io, ctx->s_compute))) return rc;
-        LRC_HIP(hipMemcpyAsync(out->counts + p0, st.io.counts + p0, np_ * 8, hipMemcpyDeviceToHost, ctx->s_compute));
+        LRC_HIP(hipMemcpyAsync(ctx->h_counts + p0, st.io.counts + p0, np_ * 8, hipMemcpyDeviceToHost, ctx->s_compute));
         LRC_HIP(hipEventRecord(ctx->ev_chunk[c], ctx->s_compute));
         p0 = p1;
     }
@@ -1631,7 +1639,7 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
         const uint64_t p1 = P * (c + 1) / chunks, r0 = p0 * N;
         LRC_HIP(hipEventSynchronize(ctx->ev_chunk[c]));
         uint64_t Kc = 0;
-        for (uint64_t k = p0; k < p1; ++k) Kc += out->counts[k];
+        for (uint64_t k = p0; k < p1; ++k) { out->counts[k] = ctx->h_counts[k]; Kc += ctx->h_counts[k]; }
         if (K + Kc > capacity) status = LRC_ERR_INVALID_ARG;        // keep counting: the caller learns the size needed
         if (status == LRC_OK && Kc) {
             hipStream_t cs = ctx->s_copy;

@@ -33,7 +33,7 @@ def engine():
 def _line_poses(name, n):
     from lidarcast import synth
     from trajectory import line_trajectory, poses_from_waypoints
-    Lx, Ly, _ = synth.SCENES[name]["size"]
+    Lx, Ly, _ = synth.scene_size(name)
     return poses_from_waypoints(line_trajectory((1.0, Ly / 2, 1.0), (Lx - 1.0, Ly / 2, 1.0), n))
 
 

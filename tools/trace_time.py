@@ -20,7 +20,7 @@ lines = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 width = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
 P = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 mesh = synth.make_scene(scene_name)
-Lx, Ly, _ = synth.SCENES[scene_name]["size"]
+Lx, Ly, _ = synth.scene_size(scene_name)
 ctx = lidarcast.Context(0)
 scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
 degs = list(np.linspace(15.0, -20.0, lines))

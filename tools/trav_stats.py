@@ -17,7 +17,7 @@ mesh = synth.make_scene(name)
 ctx = lidarcast.Context(0)
 scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles)
 sensor = bench.c3_sensor()
-Lx, Ly, _ = synth.SCENES[name]["size"]
+Lx, Ly, _ = synth.scene_size(name)
 from trajectory import line_trajectory, poses_from_waypoints  # noqa: E402
 poses = poses_from_waypoints(line_trajectory((1.0, Ly / 2, 1.0), (Lx - 1.0, Ly / 2, 1.0), 64))[:8]
 dirs = IndoorLidar(intrinsics=sensor, pose=np.eye(4)).sensor_directions()

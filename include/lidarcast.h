@@ -225,6 +225,28 @@ int lrc_scan_poses_compact(lrc_scene* scene, const double* poses16, uint64_t num
                            const double* dirs3, uint64_t rays_per_pose, double max_range,
                            const lrc_frames* out, uint64_t capacity, uint64_t* out_total);
 
+/* ---- scan of a GRID sensor: one wavefront per packet of rays ------------------------------------------------
+ * The multi-line sensor's rays form a grid: dirs3[j * width + i] = (cos a_j cos b_i, cos a_j sin b_i, sin a_j) with one
+ * elevation a_j per scan line and b_i = az0 + i * az_step covering one turn (IndoorLidar with listed elevations,
+ * lidar/indoor_lidar.py:94-131: az0 = pi, az_step = -2 pi / width).  Telling the library so lets it trace a whole packet
+ * of rays (one pose x up to 8 lines x 64 azimuths) per wavefront -- the tree is walked once per packet for the
+ * packet's frustum, and each surviving triangle runs the exact ray/triangle test only on the few rays whose direction
+ * its bounding sphere can contain (csrc/lrc_sector.h) -- instead of once per ray.  Same hit definition, same result
+ * BYTES as lrc_scan_poses_dev on the same table (tests assert it); the table itself still supplies the exact float64
+ * directions.  Needs width % 64 == 0, width >= 256 and |az_step| * width = 2 pi; the caller vouches that dirs3 HAS
+ * this structure (the Python engine derives az0 / az_step from the table and verifies every entry). */
+typedef struct lrc_grid {
+    uint32_t lines;      /* scan lines H                               */
+    uint32_t width;      /* azimuths per line W                        */
+    double   az0;        /* azimuth of column 0, radians               */
+    double   az_step;    /* azimuth increment per column, radians      */
+} lrc_grid;
+int lrc_scan_grid_dev(lrc_scene* scene, const double* d_poses16, uint64_t num_poses, const double* d_dirs3,
+                      const lrc_grid* grid, double max_range, const lrc_hits* d_out, void* stream);
+int lrc_scan_grid_compact(lrc_scene* scene, const double* poses16, uint64_t num_poses, const double* dirs3,
+                          const lrc_grid* grid, double max_range, const lrc_frames* out, uint64_t capacity,
+                          uint64_t* out_total);
+
 /* Page-locked host memory for the frame buffers above (hipHostMalloc / hipHostFree).  The caller owns it. */
 int lrc_host_alloc(lrc_ctx* ctx, uint64_t bytes, void** out_ptr);
 int lrc_host_free(lrc_ctx* ctx, void* ptr);

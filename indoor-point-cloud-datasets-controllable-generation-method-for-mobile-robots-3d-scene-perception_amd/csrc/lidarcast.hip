@@ -101,6 +101,8 @@ struct lrc_scene {
     uint32_t* d_slot_prim = nullptr;
     uint32_t* d_slot_label = nullptr;
     float4* d_prim_plane = nullptr;   // per caller's triangle row: (v0, label bits), (Ng, 0): lrc_cloud_from_prims_dev
+    float4* d_slot_sphere = nullptr;  // per leaf slot: centre of the triangle's box + bounding radius (sector_kernel)
+    const lrc_grid* cur_grid = nullptr;   // set around a grid scan (launch_trace gen == 3)
     lrc_scene_info info{};
     lrc_scan_options opts{};          // sticky opt-in options (lrc_scene_set_options)
     uint64_t launches = 0, rays = 0;
@@ -132,6 +134,7 @@ struct TraceParams {
     const float4* tris;
     const uint32_t* slot_prim;
     const uint32_t* slot_label;
+    const float4* prim_plane;  // per caller's triangle row: (v0, label bits), (Ng, 0)
     uint32_t num_nodes;
     // inputs
     const float* rays6;        // explicit rays (GEN = false)
@@ -255,7 +258,9 @@ __device__ __forceinline__ void rebuild_counts(const RebuildParams& q, uint32_t 
 
 // ---- fused write-back: everything after the closest hit is known (shared by the trace kernels) ------------------
 // best_slot = 0xFFFFFFFF: no hit.  FILTER: apply the max_range filter (scans and casts with a centre).
-template <bool FILTER_ALWAYS>
+// BY_PRIM: `best_slot` is the caller's triangle ROW (sector_kernel keys rays by (t, row)); labels and the normal then
+// come from the per-row plane table instead of the per-slot arrays -- same values.
+template <bool FILTER_ALWAYS, bool BY_PRIM = false>
 __device__ __forceinline__ void write_back(const TraceParams& p, uint64_t gid, uint32_t tid, V3 o, V3 d, double cx,
                                            double cy, double cz, float tbest, uint32_t best_slot) {
     constexpr int GEN = FILTER_ALWAYS ? 1 : 0;
@@ -285,10 +290,17 @@ __device__ __forceinline__ void write_back(const TraceParams& p, uint64_t gid, u
         if (p.min_range > 0.0) keep = keep & (dist >= p.min_range);     // opt-in; the reference never applies it
         if (keep) {
             t_out = tbest;
-            prim = p.slot_prim[best_slot];
-            label = p.slot_label[best_slot];
+            if (BY_PRIM) {
+                prim = best_slot;
+                label = __float_as_uint(p.prim_plane[(size_t)best_slot * 2].w);
+            } else {
+                prim = p.slot_prim[best_slot];
+                label = p.slot_label[best_slot];
+            }
             if (p.out.normal3 || p.out.intensity || (p.out.incident_deg && p.incident_mode == 1)) {
-                const float4 c = p.tris[(size_t)best_slot * 3 + 2];
+                float4 c;
+                if (BY_PRIM) { const float4 g = p.prim_plane[(size_t)best_slot * 2 + 1]; c = make_float4(0.f, g.x, g.y, g.z); }
+                else c = p.tris[(size_t)best_slot * 3 + 2];
                 const float len = __builtin_sqrtf(fma_(c.w, c.w, fma_(c.z, c.z, c.y * c.y)));
                 nx = c.y / len; ny = c.z / len; nz = c.w / len;
             }
@@ -626,6 +638,8 @@ __global__ __launch_bounds__(kTBlock, W) void trace_refill_kernel(const TracePar
     }
 }
 
+#include "lrc_sector.h"
+
 // ---- compaction -------------------------------------------------------------------------------
 // tile = 64 consecutive entries of one segment = one wave; tile index = seg * tps + chunk.
 
@@ -917,6 +931,7 @@ int lrc_scene_destroy(lrc_scene* s) {
     if (s->d_slot_prim) (void)hipFree(s->d_slot_prim);
     if (s->d_slot_label) (void)hipFree(s->d_slot_label);
     if (s->d_prim_plane) (void)hipFree(s->d_prim_plane);
+    if (s->d_slot_sphere) (void)hipFree(s->d_slot_sphere);
     delete s;
     return LRC_OK;
 }
@@ -990,8 +1005,28 @@ int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32
         std::memcpy(&q[3], &h.slot_label[k], 4);
         q[4] = r[9]; q[5] = r[10]; q[6] = r[11];
     }
+    // bounding sphere of every triangle's axis-aligned box (centre and half diagonal, rounded up): what
+    // sector_kernel tests against a packet of rays before it runs the exact ray/triangle test
+    std::vector<float> sphere(h.slot_prim.size() * 4, 0.0f);
+    for (size_t k = 0; k < h.slot_prim.size(); ++k) {
+        const float* r = h.tri_rec.data() + k * 12;
+        double c[3], hd2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            const double lo = std::min(std::min(r[a], r[3 + a]), r[6 + a]), hi = std::max(std::max(r[a], r[3 + a]), r[6 + a]);
+            c[a] = 0.5 * (lo + hi);
+            sphere[k * 4 + a] = (float)c[a];
+        }
+        for (int a = 0; a < 3; ++a) {       // distance from the ROUNDED centre to the farthest corner
+            const double lo = std::min(std::min(r[a], r[3 + a]), r[6 + a]), hi = std::max(std::max(r[a], r[3 + a]), r[6 + a]);
+            const double cc = (double)sphere[k * 4 + a];
+            const double e = std::max(hi - cc, cc - lo);
+            hd2 += e * e;
+        }
+        sphere[k * 4 + 3] = std::nextafter((float)std::sqrt(hd2), INFINITY);
+    }
     int rc;
-    if ((rc = upload((void**)&s->d_prim_plane, prim_plane.data(), prim_plane.size() * 4)) ||
+    if ((rc = upload((void**)&s->d_slot_sphere, sphere.data(), sphere.size() * 4)) ||
+        (rc = upload((void**)&s->d_prim_plane, prim_plane.data(), prim_plane.size() * 4)) ||
         (rc = upload((void**)&s->d_nodes, h.nodes.data(), h.nodes.size() * 4)) ||
         (rc = upload((void**)&s->d_tris, h.tri_rec.data(), h.tri_rec.size() * 4)) ||
         (rc = upload((void**)&s->d_slot_prim, h.slot_prim.data(), h.slot_prim.size() * 4)) ||
@@ -1044,6 +1079,7 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
     p.tris = s->d_tris;
     p.slot_prim = s->d_slot_prim;
     p.slot_label = s->d_slot_label;
+    p.prim_plane = s->d_prim_plane;
     p.num_nodes = (uint32_t)s->info.num_nodes;
     p.min_range = s->opts.min_range;
     p.incident_mode = s->opts.incident_mode;
@@ -1069,6 +1105,34 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
         else if (uni) { if (leafw == 2) LRC_LAUNCH(G, 2, true, false); else LRC_LAUNCH(G, 1, true, false); }  \
         else { if (leafw == 2) LRC_LAUNCH(G, 2, false, false); else LRC_LAUNCH(G, 1, false, false); }         \
     } while (0)
+    static const int no_sector = [] { const char* e = std::getenv("LRC_SECTOR"); return e ? std::atoi(e) == 0 : 0; }();
+    if (gen == 3 && (no_sector || stats)) gen = 1;        // A/B switch: the same scan through the per-ray kernel
+    if (gen == 3) {
+        const lrc_grid& g = *s->cur_grid;
+        SectorParams q{};
+        q.tp = p;
+        q.slot_sphere = s->d_slot_sphere;
+        q.H = g.lines; q.W = g.width;
+        static const int nl_env = [] { const char* e = std::getenv("LRC_SECTOR_LINES"); return e ? std::atoi(e) : 0; }();
+        uint32_t nl = nl_env > 0 ? (uint32_t)nl_env : 8u;
+        if (nl > 8u) nl = 8u;
+        if (nl > g.lines) nl = g.lines;
+        q.nl = nl;
+        q.groups = (g.lines + nl - 1) / nl;
+        q.az0 = (float)g.az0; q.az_step = (float)g.az_step;
+        q.levels = s->info.max_depth + 1u;
+        q.stack_cap = 128u * q.levels;
+        const uint64_t P = p.total / p.rays_per_pose;
+        q.num_packets = P * q.groups * (g.width / 64u);
+        if (q.num_packets > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "too many rays for one launch");
+        const size_t R = (size_t)nl * 64;
+        const size_t lds_s = R * 8 + R * 12 + (size_t)q.levels * 4 + (size_t)q.stack_cap * 4 + kLeafQ * 4 + kPairQ * 8;
+        hipLaunchKernelGGL(sector_kernel, dim3((uint32_t)q.num_packets), dim3(64), lds_s, st, q);
+        LRC_HIP(hipGetLastError());
+        s->launches += 1;
+        s->rays += p.total;
+        return LRC_OK;
+    }
     static const int refill = [] { const char* e = std::getenv("LRC_REFILL"); return e ? std::atoi(e) : 0; }();
     if (refill > 1 && gen == 1 && !stats && p.rays_per_pose % (64u * (refill >= 4 ? 4 : 2)) == 0) {
         // measured alternative: K rays per lane with private refill
@@ -1167,6 +1231,39 @@ int lrc_scan_poses_dev(lrc_scene* s, const double* d_poses16, uint64_t P, const 
     p.max_range = max_range;
     p.out = *d_out;
     return launch_trace(s, p, 1, (hipStream_t)stream);
+}
+
+static int check_grid(const char* who, const lrc_grid* g, uint64_t N) {
+    auto bad = [&](const char* m) { return fail(LRC_ERR_INVALID_ARG, std::string(who) + ": " + m); };
+    if (!g) return bad("grid is NULL");
+    if (g->lines == 0 || g->width == 0 || (uint64_t)g->lines * g->width != N) return bad("lines * width != rays_per_pose");
+    if (g->width % 64 || g->width < 256) return bad("the packet kernel needs width % 64 == 0 and width >= 256");
+    if (!(std::fabs(g->az_step) > 0.0) || std::fabs(std::fabs(g->az_step) * g->width - 6.283185307179586) > 1e-6)
+        return bad("az_step must cover one turn: |az_step| * width = 2 pi");
+    return LRC_OK;
+}
+
+int lrc_scan_grid_dev(lrc_scene* s, const double* d_poses16, uint64_t P, const double* d_dirs3, const lrc_grid* grid,
+                      double max_range, const lrc_hits* d_out, void* stream) {
+    if (!s || !d_out) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_grid_dev: NULL scene or output");
+    if (!grid) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_grid_dev: grid is NULL");
+    const uint64_t N = (uint64_t)grid->lines * grid->width;
+    int rc = check_grid("lrc_scan_grid_dev", grid, N);
+    if (rc) return rc;
+    if (P && (!d_poses16 || !d_dirs3)) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_grid_dev: poses16 or dirs3 is NULL");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    TraceParams p{};
+    p.poses16 = d_poses16;
+    p.dirs3 = d_dirs3;
+    p.rays_per_pose = N;
+    p.total = P * N;
+    p.has_center = 1;
+    p.max_range = max_range;
+    p.out = *d_out;
+    s->cur_grid = grid;
+    rc = launch_trace(s, p, 3, (hipStream_t)stream);
+    s->cur_grid = nullptr;
+    return rc;
 }
 
 // ---- host-pointer convenience wrappers ---------------------------------------------------------
@@ -1682,8 +1779,28 @@ int lrc_host_free(lrc_ctx* ctx, void* ptr) {
     return LRC_OK;
 }
 
+static int scan_compact_impl(lrc_scene* s, const double* poses16, uint64_t P, const double* dirs3, uint64_t N,
+                             const lrc_grid* grid, double max_range, const lrc_frames* out, uint64_t capacity,
+                             uint64_t* out_total);
+
 int lrc_scan_poses_compact(lrc_scene* s, const double* poses16, uint64_t P, const double* dirs3, uint64_t N,
                            double max_range, const lrc_frames* out, uint64_t capacity, uint64_t* out_total) {
+    return scan_compact_impl(s, poses16, P, dirs3, N, nullptr, max_range, out, capacity, out_total);
+}
+
+int lrc_scan_grid_compact(lrc_scene* s, const double* poses16, uint64_t P, const double* dirs3, const lrc_grid* grid,
+                          double max_range, const lrc_frames* out, uint64_t capacity, uint64_t* out_total) {
+    if (out_total) *out_total = 0;
+    if (!grid) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_grid_compact: grid is NULL");
+    const uint64_t N = (uint64_t)grid->lines * grid->width;
+    int rc = check_grid("lrc_scan_grid_compact", grid, N);
+    if (rc) return rc;
+    return scan_compact_impl(s, poses16, P, dirs3, N, grid, max_range, out, capacity, out_total);
+}
+
+static int scan_compact_impl(lrc_scene* s, const double* poses16, uint64_t P, const double* dirs3, uint64_t N,
+                             const lrc_grid* grid, double max_range, const lrc_frames* out, uint64_t capacity,
+                             uint64_t* out_total) {
     if (out_total) *out_total = 0;
     if (!s || !out) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_poses_compact: NULL scene or output");
     const uint64_t n = P * N;
@@ -1707,7 +1824,10 @@ int lrc_scan_poses_compact(lrc_scene* s, const double* poses16, uint64_t P, cons
     p.total = n;
     p.has_center = 1;
     p.max_range = max_range;
-    return frames_finish(s, p, 1, st, P, N, out, capacity, out_total);
+    s->cur_grid = grid;
+    rc = frames_finish(s, p, grid ? 3 : 1, st, P, N, out, capacity, out_total);
+    s->cur_grid = nullptr;
+    return rc;
 }
 
 int lrc_scan_angles_dev(lrc_scene* s, const double* d_poses16, uint64_t P, const double* d_angles2,

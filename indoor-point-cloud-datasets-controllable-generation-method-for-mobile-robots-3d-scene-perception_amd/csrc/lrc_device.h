@@ -105,6 +105,34 @@ LRC_DI bool tri_hit(V3 o, V3 d, const RaySlab& s, V3 v0, V3 v1, V3 v2, V3 ng, fl
     return true;
 }
 
+// tri_hit for callers that have no RaySlab at hand (sector_kernel tests a few rays against one triangle): identical
+// conditions and arithmetic; the ray's slab constants are formed only for the rare pair that passes the
+// Moeller-Trumbore conditions, which is when the box clause needs them.
+LRC_DI bool tri_hit_lazy(V3 o, V3 d, V3 v0, V3 v1, V3 v2, V3 ng, float& t_out) {
+    V3 e1 = sub3(v0, v1);
+    V3 e2 = sub3(v2, v0);
+    V3 c = sub3(v0, o);
+    V3 r = cross3(c, d);
+    float den = dot3(ng, d);
+    float aden = __builtin_fabsf(den);
+    uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+    float u = xorsign(dot3(r, e2), sgn);
+    float v = xorsign(dot3(r, e1), sgn);
+    float tt = xorsign(dot3(ng, c), sgn);
+    bool ok = (den != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= aden) & (tt > 0.0f);
+    if (!ok) return false;
+    float t = tt / aden;
+    const RaySlab s = make_slab(o, d);
+    float lox = min2(min2(v0.x, v1.x), v2.x), hix = max2(max2(v0.x, v1.x), v2.x);
+    float loy = min2(min2(v0.y, v1.y), v2.y), hiy = max2(max2(v0.y, v1.y), v2.y);
+    float loz = min2(min2(v0.z, v1.z), v2.z), hiz = max2(max2(v0.z, v1.z), v2.z);
+    float tn, tf;
+    slab_interval(s, lox, loy, loz, hix, hiy, hiz, tn, tf);
+    if (!((tn <= t) & (t <= tf) & (t < __builtin_inff()))) return false;
+    t_out = t;
+    return true;
+}
+
 // A ray takes part in the cast only if its six components are finite (bit test: immune to -fno-honor-nans).  Anything
 // else is reported as a miss without touching the tree, so no comparison ever sees a NaN (include/lidarcast.h,
 // "finite-ray contract"; the oracle applies the same rule).

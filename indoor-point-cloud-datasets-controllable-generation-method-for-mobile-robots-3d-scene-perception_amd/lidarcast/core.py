@@ -12,7 +12,8 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import LRC_STATS_WORDS, LrcCompactIO, LrcFrames, LrcHits, LrcScanOptions, LrcSceneInfo, check
+from ._capi import (LRC_STATS_WORDS, LrcCompactIO, LrcFrames, LrcGrid, LrcHits, LrcScanOptions, LrcSceneInfo,
+                    check)
 
 ATTRS = ("t", "prim", "normal3", "point3", "sem", "ins", "incident_deg")
 _NP_SPEC = {
@@ -373,10 +374,17 @@ class Scene:
         out["total"] = int(total)
         return out
 
-    def scan_poses_compact(self, poses, dirs, max_range, want=("point3", "sem", "ins"), capacity=None):
+    @staticmethod
+    def _grid_struct(grid):
+        g = LrcGrid()
+        g.lines, g.width, g.az0, g.az_step = int(grid[0]), int(grid[1]), float(grid[2]), float(grid[3])
+        return g
+
+    def scan_poses_compact(self, poses, dirs, max_range, want=("point3", "sem", "ins"), capacity=None, grid=None):
         """Pose-batched scan straight to the kept rows of every pose (lrc_scan_poses_compact): dict of (K, ...)
         arrays over page-locked memory + ``counts`` (P,) int64 + ``total`` K.  Frame p = rows
-        [counts[:p].sum(), counts[:p+1].sum())."""
+        [counts[:p].sum(), counts[:p+1].sum()).  ``grid`` = (lines, width, az0, az_step) of a table that is a
+        (scan line x azimuth) grid selects the packet kernel (lrc_scan_grid_compact): same bytes, faster."""
         poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 16)
         dirs = np.ascontiguousarray(dirs, dtype=np.float64)
         if dirs.ndim != 2 or dirs.shape[1] != 3:
@@ -384,8 +392,13 @@ class Scene:
         P, N = poses.shape[0], dirs.shape[0]
         fr, counts, bufs, cap = self._frames_begin(P, P * N, want, capacity)
         total = C.c_uint64(0)
-        check(self._lib.lrc_scan_poses_compact(self._h, _ptr(poses), P, _ptr(dirs), N, float(max_range),
-                                               C.byref(fr), cap, C.byref(total)), "lrc_scan_poses_compact")
+        if grid is not None:
+            g = self._grid_struct(grid)
+            check(self._lib.lrc_scan_grid_compact(self._h, _ptr(poses), P, _ptr(dirs), C.byref(g), float(max_range),
+                                                  C.byref(fr), cap, C.byref(total)), "lrc_scan_grid_compact")
+        else:
+            check(self._lib.lrc_scan_poses_compact(self._h, _ptr(poses), P, _ptr(dirs), N, float(max_range),
+                                                   C.byref(fr), cap, C.byref(total)), "lrc_scan_poses_compact")
         return self._frames_end(counts, bufs, total.value)
 
     def scan_angles_compact(self, poses, angles, keep, max_range, want=("point3", "sem", "ins"), capacity=None):
@@ -434,8 +447,14 @@ class Scene:
                                      float(max_range), C.byref(hits.struct), C.c_void_p(int(stream))),
               "lrc_cast_dev")
 
-    def scan_poses_dev(self, poses_t, dirs_t, hits, max_range, stream=0):
+    def scan_poses_dev(self, poses_t, dirs_t, hits, max_range, stream=0, grid=None):
         P, N = poses_t.shape[0], dirs_t.shape[0]
+        if grid is not None:       # the table is a (scan line x azimuth) grid: packet kernel, same bytes
+            g = self._grid_struct(grid)
+            check(self._lib.lrc_scan_grid_dev(self._h, C.c_void_p(poses_t.data_ptr()), P,
+                                              C.c_void_p(dirs_t.data_ptr()), C.byref(g), float(max_range),
+                                              C.byref(hits.struct), C.c_void_p(int(stream))), "lrc_scan_grid_dev")
+            return
         check(self._lib.lrc_scan_poses_dev(self._h, C.c_void_p(poses_t.data_ptr()), P,
                                            C.c_void_p(dirs_t.data_ptr()), N, float(max_range),
                                            C.byref(hits.struct), C.c_void_p(int(stream))),

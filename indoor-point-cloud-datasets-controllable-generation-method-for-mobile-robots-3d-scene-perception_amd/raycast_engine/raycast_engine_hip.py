@@ -64,6 +64,8 @@ class RaycastEngineHIP(RaycastEngineBase):
         self.ctx = Context(device)          # raises when there is no GPU / no library
         self._scenes = {}                   # id(mesh) -> (weakref or None, fingerprint, Scene)
         self._dir_tables = {}
+        self._grids = {}
+        self.min_packets = 1024             # scans with fewer ray packets than this stay on the per-ray kernel
         self._max_cached = int(max_cached_scenes)
 
     # ---- scene cache: build once per mesh ---------------------------------------------------------
@@ -140,6 +142,49 @@ class RaycastEngineHIP(RaycastEngineBase):
             self._dir_tables[key] = tab
         return tab
 
+    def _grid_of(self, intrinsics, num_poses=1):
+        """(lines, width, az0, az_step) when the sensor's direction table is a (scan line x azimuth) grid the packet
+        kernel can take and the scan is large enough to fill the GPU with packets, else None (per-ray kernel).
+        The structure is derived from the table and verified entry by entry, once per table."""
+        if getattr(intrinsics, "vertical_degrees", None) is None:
+            return None
+        tab = self._direction_table(intrinsics)
+        key = id(tab)
+        ent = self._grids.get(key)
+        if ent is None or ent[0] is not tab:
+            ent = (tab, self._derive_grid(tab, int(intrinsics.horizontal_res)))
+            if len(self._grids) >= 8:
+                self._grids.pop(next(iter(self._grids)))
+            self._grids[key] = ent
+        grid = ent[1]
+        if grid is None:
+            return None
+        packets = int(num_poses) * ((grid[0] + 7) // 8) * (grid[1] // 64)
+        return grid if packets >= self.min_packets else None
+
+    @staticmethod
+    def _derive_grid(tab, W):
+        W = max(1, int(W))
+        if W % 64 or W < 256 or len(tab) % W:
+            return None
+        H = len(tab) // W
+        t = tab.reshape(H, W, 3)
+        if not np.isfinite(t).all() or not (t[:, :, 2] == t[:, :1, 2]).all():
+            return None                                        # one elevation per line, exactly
+        ch = np.sqrt(t[:, 0, 0] ** 2 + t[:, 0, 1] ** 2)
+        if (ch < 1e-6).any():
+            return None                                        # a line looking straight up / down has no azimuth
+        az = np.arctan2(t[0, :, 1], t[0, :, 0])
+        step = np.angle(np.exp(1j * (az[1] - az[0])))
+        if abs(abs(step) * W - 2 * np.pi) > 1e-9:
+            return None
+        step = float(np.sign(step)) * 2 * np.pi / W            # one turn exactly
+        model = az[0] + step * np.arange(W)
+        ok = np.abs(t[:, :, 0] - ch[:, None] * np.cos(model)[None, :]).max() < 1e-12 and \
+            np.abs(t[:, :, 1] - ch[:, None] * np.sin(model)[None, :]).max() < 1e-12 and \
+            np.abs(ch ** 2 + t[:, 0, 2] ** 2 - 1).max() < 1e-12
+        return (H, W, float(az[0]), float(step)) if ok else None
+
     def lidar_intersect_mesh(self, lidar, mesh):
         from lidar import IndoorLidar
         scene = self.scene_for(mesh)
@@ -187,7 +232,8 @@ class RaycastEngineHIP(RaycastEngineBase):
         if not hasattr(intrinsics, "horizontal_res") or hasattr(intrinsics, "swing_amplitude"):
             raise ValueError("sensor has no pose-independent direction table")
         return self.scene_for(mesh).scan_poses_compact(poses, self._direction_table(intrinsics),
-                                                       intrinsics.max_range, want=want)
+                                                       intrinsics.max_range, want=want,
+                                                       grid=self._grid_of(intrinsics, len(poses)))
 
     def scan_frames_dual_axis(self, lidars, mesh, want=("point3", "sem", "ins")):
         """Opt-in fast path of the dual-axis sensor: the noisy scan angles and the dropout mask are drawn on the host
@@ -251,7 +297,8 @@ class RaycastEngineHIP(RaycastEngineBase):
             hits.struct.tile_count = g.tile_count.data_ptr()
         d_poses = torch.from_numpy(block_poses).to(dev)
         d_dirs = torch.from_numpy(np.ascontiguousarray(dirs)).to(dev)
-        scene.scan_poses_dev(d_poses, d_dirs, hits, intrinsics.max_range, torch.cuda.current_stream().cuda_stream)
+        scene.scan_poses_dev(d_poses, d_dirs, hits, intrinsics.max_range, torch.cuda.current_stream().cuda_stream,
+                             grid=self._grid_of(intrinsics, p_loc))
         torch.cuda.current_stream().synchronize()       # the slab is complete before the collective reads it
 
     def cloud_from_gather(self, g, intrinsics, padded_poses, mesh):

@@ -396,3 +396,115 @@ def test_simulator_export_reads_the_annotation_files(tmp_path, engine):
     assert np.array_equal(out["sem"], al[j].astype(np.uint16)) and np.array_equal(out["ins"], ai[j].astype(np.uint16))   # ... the files decide
     assert np.array_equal(np.stack([out["red"], out["green"], out["blue"]], 1), (col[j] * 255).astype(np.uint8))
     assert len(np.unique(out["red"])) > 50                                  # not the default grey
+
+
+# ---- the packet kernel: same bytes as the per-ray kernel ----------------------------------------------------------
+def _rot(yaw, pitch, roll):
+    cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    return Rz @ Ry @ Rx
+
+
+def test_packet_kernel_is_bit_identical(engine):
+    """lrc_scan_grid_dev (one wavefront per packet of rays: frustum traversal + per-triangle candidate rays, LDS
+    atomic min) against lrc_scan_poses_dev (one lane per ray) on the same tables: every output attribute must agree
+    bit for bit -- tessellated and rough rooms, giant triangles (a cube), a triangle soup, a single quad; yawed, pitched
+    and rolled sensors; steep scan lines; origins millimetres from a wall; line counts that do not fill a packet."""
+    import torch
+    import lidarcast
+    from lidar import Indoor8LineLidarIntrinsics, IndoorLidar
+    from lidarcast import synth
+    from lidarcast.synth import TriangleMesh
+    from raycast_engine.raycast_engine_hip import RaycastEngineHIP
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    v, f = __import__("helpers").random_soup(3000, 5, extent=3.0, size=0.4)
+    cube = synth.unit_cube(-2.0, 2.5)
+    scenes = {
+        "room": synth.make_room(size=(4, 3, 2.5), num_boxes=4, seed=5, cell=0.04),
+        "rough": synth.make_room(size=(4, 3, 2.5), num_boxes=3, seed=8, rough=True),
+        "cube": TriangleMesh(cube.vertices + 0.25, cube.triangles),
+        "soup": TriangleMesh(v + 1.0, f),
+        "quad": synth.quad(z=1.7, half=3.0),
+    }
+    sensors = {
+        "8x512": Indoor8LineLidarIntrinsics(vertical_res=8, horizontal_res=512, max_range=20.0,
+                                            vertical_degrees=[15.0, 10.0, 5.0, 0.0, -5.0, -10.0, -15.0, -20.0]),
+        "32x2048": sensor_32x2048(),
+        "steep5x256": Indoor8LineLidarIntrinsics(vertical_res=5, horizontal_res=256, max_range=3.0,
+                                                 vertical_degrees=[75.0, 40.0, 1.0, -33.0, -80.0]),
+        "11x320": Indoor8LineLidarIntrinsics(vertical_res=11, horizontal_res=320, max_range=50.0,
+                                             vertical_degrees=list(np.linspace(25, -35, 11))),
+    }
+    poses = []
+    for (x, y, z, yaw, pitch, roll) in [(1.0, 1.2, 1.0, 0.0, 0.0, 0.0), (2.2, 1.6, 1.1, 0.7, 0.0, 0.0),
+                                        (3.0, 1.0, 0.6, -2.5, 0.3, -0.2), (0.03, 1.5, 1.2, 3.1, 0.0, 0.0),
+                                        (2.0, 0.004, 2.4, 1.3, -0.5, 1.0), (1.5, 1.5, 1.7, 0.2, 0.0, 0.0)]:
+        m = np.eye(4)
+        m[:3, :3] = _rot(yaw, pitch, roll)
+        m[:3, 3] = (x, y, z)
+        poses.append(m)
+    poses = np.stack(poses)
+    want = ("t", "prim", "normal3", "point3", "sem", "ins", "incident_deg", "tile_count")
+    checked = 0
+    for sname, mesh in scenes.items():
+        scene = lidarcast.Scene(engine.ctx, mesh.vertices, mesh.triangles, getattr(mesh, "triangle_sem", None),
+                                getattr(mesh, "triangle_ins", None))
+        for kname, k in sensors.items():
+            dirs = IndoorLidar(k, np.eye(4)).sensor_directions()
+            grid = RaycastEngineHIP._derive_grid(dirs, k.horizontal_res)
+            assert grid is not None, kname
+            ps = poses[:2] if kname == "32x2048" else poses
+            P, N = len(ps), len(dirs)
+            d_poses, d_dirs = torch.from_numpy(ps.reshape(P, 16)).to(dev), torch.from_numpy(dirs).to(dev)
+            a = lidarcast.DeviceHits(P * N, dev, want=want)
+            b = lidarcast.DeviceHits(P * N, dev, want=want)
+            scene.scan_poses_dev(d_poses, d_dirs, a, k.max_range, st)
+            scene.scan_poses_dev(d_poses, d_dirs, b, k.max_range, st, grid=grid)
+            torch.cuda.synchronize()
+            for att in want:
+                x, y = a[att].cpu().numpy(), b[att].cpu().numpy()
+                ne = x.view(np.uint8) != y.view(np.uint8)
+                assert not ne.any(), (f"{sname} / {kname}: {att} differs in {int(ne.reshape(len(x), -1).any(1).sum())} of "
+                                      f"{len(x)} entries, first at {np.argwhere(ne.reshape(len(x), -1).any(1))[0]}")
+            hit = np.isfinite(a["t"].cpu().numpy())
+            if sname in ("room", "rough", "cube"):
+                assert hit.mean() > 0.3
+            checked += int(hit.sum())
+        scene.close()
+    assert checked > 500000
+
+
+def test_packet_kernel_full_size_c3(engine):
+    """C3 at full size through the packet kernel: all 4.19 M rays' records equal the per-ray kernel's, byte for byte
+    (SHA-256 of every attribute), through both the device and the frame-producing entry points."""
+    import torch
+    import bench
+    import lidarcast
+    from lidarcast import synth
+    mesh = synth.make_scene(bench.SCENE)
+    scene = engine.scene_for(mesh)
+    sensor = bench.c3_sensor()
+    poses = bench.c3_poses(0, 1)
+    dirs = engine._direction_table(sensor)
+    grid = engine._grid_of(sensor, len(poses))
+    assert grid == (32, 2048, np.pi, -2 * np.pi / 2048)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    P, N = len(poses), len(dirs)
+    want = ("t", "prim", "normal3", "point3", "sem", "ins", "tile_count")
+    d_poses, d_dirs = torch.from_numpy(poses.reshape(P, 16)).to(dev), torch.from_numpy(dirs).to(dev)
+    dig = []
+    for g in (None, grid):
+        h = lidarcast.DeviceHits(P * N, dev, want=want)
+        scene.scan_poses_dev(d_poses, d_dirs, h, sensor.max_range, st, grid=g)
+        torch.cuda.synchronize()
+        dig.append({a: hashlib.sha256(h[a].cpu().numpy().tobytes()).hexdigest() for a in want})
+    assert dig[0] == dig[1]
+    fa = scene.scan_poses_compact(poses, dirs, sensor.max_range, want=("point3", "sem", "ins", "index"))
+    fb = scene.scan_poses_compact(poses, dirs, sensor.max_range, want=("point3", "sem", "ins", "index"), grid=grid)
+    assert fa["total"] == fb["total"] > 4e6 and np.array_equal(fa["counts"], fb["counts"])
+    for a in ("point3", "sem", "ins", "index"):
+        assert_bit_equal(fa[a], fb[a], a)

@@ -32,16 +32,21 @@ n = P * len(dirs)
 hits = lidarcast.DeviceHits(n, dev, want=("t", "prim", "normal3", "point3", "sem", "ins", "tile_count"))
 d_poses, d_dirs = torch.from_numpy(poses.reshape(P, 16)).to(dev), torch.from_numpy(dirs).to(dev)
 st = torch.cuda.current_stream().cuda_stream
+grid = None
+if os.environ.get("LRC_GRID", "0") != "0":      # packet kernel (lrc_scan_grid_dev)
+    from raycast_engine.raycast_engine_hip import RaycastEngineHIP
+    grid = RaycastEngineHIP._derive_grid(dirs, width)
+    assert grid is not None, "the table is not a grid the packet kernel takes"
 for _ in range(5):
-    scene.scan_poses_dev(d_poses, d_dirs, hits, k.max_range, st)
+    scene.scan_poses_dev(d_poses, d_dirs, hits, k.max_range, st, grid=grid)
 torch.cuda.synchronize()
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
 for a, b in ev:
     a.record()
-    scene.scan_poses_dev(d_poses, d_dirs, hits, k.max_range, st)
+    scene.scan_poses_dev(d_poses, d_dirs, hits, k.max_range, st, grid=grid)
     b.record()
 torch.cuda.synchronize()
 ms = sorted(a.elapsed_time(b) for a, b in ev)
 chk = int(hits["prim"].to(torch.int64).sum().item())
-print(f"{scene_name} {lines}x{width} x{P}: {n} rays, median {ms[len(ms)//2]:.4f} ms, min {ms[0]:.4f} ms, "
+print(f"{'packet ' if grid else ''}{scene_name} {lines}x{width} x{P}: {n} rays, median {ms[len(ms)//2]:.4f} ms, min {ms[0]:.4f} ms, "
       f"{n / ms[len(ms)//2] / 1e6:.2f} G rays/s, checksum {chk}")

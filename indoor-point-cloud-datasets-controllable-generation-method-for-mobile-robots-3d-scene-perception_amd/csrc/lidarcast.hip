@@ -1127,7 +1127,22 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
         if (q.num_packets > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "too many rays for one launch");
         const size_t R = (size_t)nl * 64;
         const size_t lds_s = R * 8 + R * 12 + (size_t)q.levels * 4 + (size_t)q.stack_cap * 4 + kLeafQ * 4 + kPairQ * 8;
-        hipLaunchKernelGGL(sector_kernel, dim3((uint32_t)q.num_packets), dim3(64), lds_s, st, q);
+        static const int sdiag = [] { const char* e = std::getenv("LRC_SECTOR_DIAG"); return e ? std::atoi(e) : 0; }();
+        if (sdiag) {      // diagnostic build: work totals of this launch, printed to stderr (tools only)
+            unsigned long long* d = nullptr;
+            LRC_HIP(hipMalloc((void**)&d, kSectorDiagWords * 8));
+            LRC_HIP(hipMemsetAsync(d, 0, kSectorDiagWords * 8, st));
+            q.diag = d;
+            hipLaunchKernelGGL(sector_kernel<true>, dim3((uint32_t)q.num_packets), dim3(64), lds_s, st, q);
+            unsigned long long h[kSectorDiagWords];
+            LRC_HIP(hipStreamSynchronize(st));
+            LRC_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+            (void)hipFree(d);
+            std::fprintf(stderr, "[sector diag] packets %llu lines/packet %u: node rounds %llu, nodes %llu, leaves %llu, "
+                                 "triangles %llu, pairs %llu, pair rounds %llu, candidate rays %llu, accepted %llu\n",
+                         (unsigned long long)q.num_packets, nl, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+        } else
+        hipLaunchKernelGGL(sector_kernel<false>, dim3((uint32_t)q.num_packets), dim3(64), lds_s, st, q);
         LRC_HIP(hipGetLastError());
         s->launches += 1;
         s->rays += p.total;

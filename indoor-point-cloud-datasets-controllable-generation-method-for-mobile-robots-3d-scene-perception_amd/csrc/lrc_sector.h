@@ -36,7 +36,12 @@ struct SectorParams {
     uint32_t stack_cap;             // entries of the level-segmented stack: 128 * (max_depth + 1)
     uint32_t levels;                // max_depth + 1
     uint64_t num_packets;
+    unsigned long long* diag;       // DIAG build: totals over all packets (see kSectorDiagWords)
 };
+
+// DIAG counters: node rounds, nodes popped, leaves taken, triangles sphere-tested, pairs emitted, pair rounds,
+// candidate rays tested, exact-test hits
+constexpr int kSectorDiagWords = 8;
 
 constexpr int kLeafQ = 256, kPairQ = 128;
 
@@ -47,7 +52,9 @@ __device__ __forceinline__ float uni(float x) { return __int_as_float(__builtin_
 
 // LDS layout (dynamic): keys[R] u64 | dtab[R*3] f32 | level_cnt[levels] u32 | stack[stack_cap] u32 | leafq[kLeafQ] u32 |
 //                       pairq[kPairQ] SectorPair          with R = nl * 64
+template <bool DIAG>
 __global__ __launch_bounds__(64) void sector_kernel(const SectorParams q) {
+    uint32_t dg[kSectorDiagWords] = {0, 0, 0, 0, 0, 0, 0, 0};
     extern __shared__ unsigned long long s_raw[];
     const TraceParams& p = q.tp;
     const uint32_t lane = threadIdx.x;
@@ -175,6 +182,7 @@ __global__ __launch_bounds__(64) void sector_kernel(const SectorParams q) {
         SectorPair pr{0u, 0u};
         if (lane < m) pr = s_pairq[npair - 1u - lane];
         npair -= m;
+        if (DIAG) dg[5] += 1;
         if (lane < m) {
             const uint32_t slot = pr.slot;
             const uint32_t il_lo = pr.lo_hi_mask & 0xFFu, il_hi = (pr.lo_hi_mask >> 8) & 0xFFu, lmask = pr.lo_hi_mask >> 16;
@@ -189,7 +197,9 @@ __global__ __launch_bounds__(64) void sector_kernel(const SectorParams q) {
                     const V3 d{s_dtab[r * 3], s_dtab[r * 3 + 1], s_dtab[r * 3 + 2]};
                     if (!finite_ray(o, d)) continue;
                     float t;
+                    if (DIAG) dg[6] += 1;
                     if (tri_hit_lazy(o, d, v0, v1, v2, ng, t)) {
+                        if (DIAG) dg[7] += 1;
                         if (prim == 0xFFFFFFFFu) prim = p.slot_prim[slot];
                         const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | prim;
                         atomicMin(&s_keys[r], key);
@@ -205,6 +215,7 @@ __global__ __launch_bounds__(64) void sector_kernel(const SectorParams q) {
         uint32_t enc = 0u;
         if (lane < m) enc = s_leafq[nleaf - 1u - lane];
         nleaf -= m;
+        if (DIAG) dg[2] += lane < m ? 1 : 0;
         const uint32_t first = enc >> 3, cnt = enc & 7u;
         for (uint32_t k = 0; k < 4u; ++k) {
             if (__builtin_amdgcn_ballot_w64(k < cnt) == 0ull) break;
@@ -212,6 +223,7 @@ __global__ __launch_bounds__(64) void sector_kernel(const SectorParams q) {
             bool emit = false;
             SectorPair pr{0u, 0u};
             if (k < cnt) {
+                if (DIAG) dg[3] += 1;
                 const uint32_t slot = first + k;
                 const float4 sp = q.slot_sphere[slot];
                 const float vx = sp.x - o.x, vy = sp.y - o.y, vz = sp.z - o.z;
@@ -261,6 +273,7 @@ __global__ __launch_bounds__(64) void sector_kernel(const SectorParams q) {
                 pr.slot = slot;
                 pr.lo_hi_mask = il_lo | (il_hi << 8) | (lmask << 16);
             }
+            if (DIAG) dg[4] += emit ? 1 : 0;
             const unsigned long long bm = __builtin_amdgcn_ballot_w64(emit);
             if (emit) s_pairq[npair + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = pr;
             npair += (uint32_t)__popcll(bm);
@@ -285,6 +298,7 @@ __global__ __launch_bounds__(64) void sector_kernel(const SectorParams q) {
             continue;
         }
         const uint32_t m = cnt_cur < 64u ? cnt_cur : 64u;
+        if (DIAG) { dg[0] += lane == 0 ? 1 : 0; dg[1] += lane < m ? 1 : 0; }
         int ref = -1;
         if (lane < m) ref = (int)s_stack[base_cur + cnt_cur - 1u - lane];
         bool in0 = false, in1 = false;
@@ -318,6 +332,17 @@ __global__ __launch_bounds__(64) void sector_kernel(const SectorParams q) {
         __syncthreads();
     }
 
+    if (DIAG) {
+        if (q.diag) {
+            if (lane != 0) { dg[5] = 0; }
+#pragma unroll
+            for (int k = 0; k < kSectorDiagWords; ++k) {
+                unsigned int v = dg[k];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if (lane == 0) atomicAdd(&q.diag[k], (unsigned long long)v);
+            }
+        }
+    }
     // ---- write-back, one pass per scan line of the packet ----
     for (uint32_t jl = 0; jl < nlines; ++jl) {
         const uint64_t gid = pose * N + (uint64_t)(j0 + jl) * q.W + i0 + lane;

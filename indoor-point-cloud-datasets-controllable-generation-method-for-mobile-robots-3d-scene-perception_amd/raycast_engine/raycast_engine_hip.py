@@ -65,7 +65,11 @@ class RaycastEngineHIP(RaycastEngineBase):
         self._scenes = {}                   # id(mesh) -> (weakref or None, fingerprint, Scene)
         self._dir_tables = {}
         self._grids = {}
-        self.min_packets = 1024             # scans with fewer ray packets than this stay on the per-ray kernel
+        # The packet kernel (lrc_scan_grid_*, csrc/lrc_sector.h) returns the same bytes as the per-ray kernel and is
+        # kept as a measured alternative: on the benchmark scenes it is 3-10x SLOWER, so it is
+        # off unless asked for.
+        self.packet_kernel = False
+        self.min_packets = 1024             # with packet_kernel: smaller scans stay on the per-ray kernel anyway
         self._max_cached = int(max_cached_scenes)
 
     # ---- scene cache: build once per mesh ---------------------------------------------------------
@@ -146,7 +150,7 @@ class RaycastEngineHIP(RaycastEngineBase):
         """(lines, width, az0, az_step) when the sensor's direction table is a (scan line x azimuth) grid the packet
         kernel can take and the scan is large enough to fill the GPU with packets, else None (per-ray kernel).
         The structure is derived from the table and verified entry by entry, once per table."""
-        if getattr(intrinsics, "vertical_degrees", None) is None:
+        if not self.packet_kernel or getattr(intrinsics, "vertical_degrees", None) is None:
             return None
         tab = self._direction_table(intrinsics)
         key = id(tab)

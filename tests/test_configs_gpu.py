@@ -489,7 +489,10 @@ def test_packet_kernel_full_size_c3(engine):
     sensor = bench.c3_sensor()
     poses = bench.c3_poses(0, 1)
     dirs = engine._direction_table(sensor)
+    assert engine._grid_of(sensor, len(poses)) is None              # off by default: a measured alternative
+    engine.packet_kernel = True
     grid = engine._grid_of(sensor, len(poses))
+    engine.packet_kernel = False
     assert grid == (32, 2048, np.pi, -2 * np.pi / 2048)
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream

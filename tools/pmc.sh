@@ -6,7 +6,7 @@ set -u
 FAILED=0
 TAG=${1:-pmc}
 PAT=${2:-trace_kernel}
-ARGS=${PMC_ARGS:---steps 3 --warmup 1 --no-cpu-baseline}
+ARGS=${PMC_ARGS:---steps 3 --warmup 1 --no-cpu-baseline --no-caller-path}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

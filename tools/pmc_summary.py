@@ -28,12 +28,12 @@ import json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry  # noqa: E402
 for k, cs in acc.items():
-    if "trace_kernel<1" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs and "SQ_INSTS_VALU" in cs:
+    if ("trace_kernel<1" in k or "trace_refill" in k) and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs and "SQ_INSTS_VALU" in cs:
         mean = lambda v: sum(v) / len(v)
         out = {"kernel": k, "source_sha256": entry.source_fingerprint(),
                "FETCH_SIZE_KB": mean(cs["FETCH_SIZE"]), "WRITE_SIZE_KB": mean(cs["WRITE_SIZE"]),
                "rays_per_launch": 4194304, "scene": os.environ.get("PMC_SCENE", "synth_A6_office2"),
-               "command": "bench.py " + os.environ.get("PMC_ARGS", "--steps 3 --warmup 1 --no-cpu-baseline"),
+               "command": "bench.py " + os.environ.get("PMC_ARGS", "--steps 3 --warmup 1 --no-cpu-baseline --no-caller-path"),
                "counters": {c: mean(v) for c, v in sorted(cs.items())}}
         with open(os.path.join(root, "pmc.json"), "w") as f:
             json.dump(out, f, indent=1)

@@ -66,7 +66,11 @@ class AutoTrajectoryGenerator:
     def _occupancy(self, mesh):
         """Mesh vertices resident on the GPU (one upload per mesh)."""
         v = np.asarray(mesh.vertices)
-        key = (id(mesh), v.shape)
+        # id() alone can be recycled by a new mesh of the same size (a batch loop over scenes), and a mesh can be edited
+        # in place: key on the content too -- a full hash of the vertices costs milliseconds next to a plan of seconds
+        import hashlib
+        key = (id(mesh), v.shape, hashlib.blake2b(np.ascontiguousarray(v).view(np.uint8).reshape(-1).tobytes(),
+                                                  digest_size=16).hexdigest())
         if self._occ is None or self._occ_key != key:
             import lidarcast
             if self._ctx is None:

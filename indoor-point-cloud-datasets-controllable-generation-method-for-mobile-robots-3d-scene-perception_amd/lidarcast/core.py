@@ -351,6 +351,8 @@ class Scene:
         return outs
 
     # ---- straight to frames ---------------------------------------------------------------------
+    PINNED_MIN_BYTES = 4 << 20      # frame arrays at least this large are taken from the page-locked pool
+
     def _frames_begin(self, P, n, want, capacity):
         cap = int(n if capacity is None else capacity)
         fr = LrcFrames()
@@ -362,8 +364,12 @@ class Scene:
                 raise ValueError(f"unknown frame attribute {a!r}")
             dt, tail = _FRAME_SPEC[a]
             width = int(np.prod(tail, dtype=np.int64)) if tail else 1
-            raw = self.ctx.pinned.take(max(cap, 1) * width * np.dtype(dt).itemsize)
-            bufs[a] = raw[:cap * width * np.dtype(dt).itemsize].view(dt).reshape((cap,) + tail)
+            nbytes = max(cap, 1) * width * np.dtype(dt).itemsize
+            if nbytes >= self.PINNED_MIN_BYTES:
+                raw = self.ctx.pinned.take(nbytes)
+                bufs[a] = raw[:cap * width * np.dtype(dt).itemsize].view(dt).reshape((cap,) + tail)
+            else:       # a single pose's worth: page-locking a fresh buffer would cost more than the staged copy saves
+                bufs[a] = np.empty((cap,) + tail, dtype=dt)
             setattr(fr, a, bufs[a].ctypes.data)
         return fr, counts, bufs, cap
 

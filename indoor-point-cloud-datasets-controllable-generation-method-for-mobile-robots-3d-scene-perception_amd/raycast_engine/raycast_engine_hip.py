@@ -195,8 +195,13 @@ class RaycastEngineHIP(RaycastEngineBase):
         if type(lidar) is IndoorLidar and (lidar.intrinsics.vertical_degrees is None or len(lidar.intrinsics.vertical_degrees)):
             # this package's own multi-line sensor: rays are generated in the kernel from the direction table
             # (bit-identical to lidar.get_rays(), rotated poses included) instead of on the host
-            out = scene.scan_poses(np.asarray(lidar.pose, dtype=np.float64)[None], self._direction_table(lidar.intrinsics),
-                                   lidar.intrinsics.max_range, want=("t", "point3", "incident_deg"))
+            # ... and compacted in HBM: only the kept points and angles cross PCIe (lrc_scan_poses_compact)
+            fr = scene.scan_poses_compact(np.asarray(lidar.pose, dtype=np.float64)[None],
+                                          self._direction_table(lidar.intrinsics), lidar.intrinsics.max_range,
+                                          want=("point3", "incident_deg"))
+            if fr["total"] > 0:
+                return fr["point3"], fr["incident_deg"]
+            return np.empty((0, 3), dtype=np.float32), np.empty(0)
         else:
             rays = lidar.get_rays()
             self._check_rays(rays)

@@ -71,11 +71,15 @@ def test_scan_frames_equals_fixed_stride_records(engine):
         views = engine.split_frames(fr, "point3")
         assert len(views) == 5 and all(np.shares_memory(v, fr["point3"]) or len(v) == 0 for v in views)
         assert_bit_equal(views[3], rec["point3"][3][keep[3]])
-    # page-locked buffers: a second scan after the first result was dropped allocates nothing new
+    # page-locked buffers (arrays of >= 4 MB): a second scan after the first result was dropped allocates nothing new
     scene = engine.scene_for(mesh)
-    dirs = engine._direction_table(k)
+    big = sensor_32x2048()
+    dirs = engine._direction_table(big)
+    poses = np.stack([pose(0.8 + 0.4 * i, 1.4, 1.0, 0.3 * i) for i in range(6)])
+    k = big
     a = scene.scan_poses_compact(poses, dirs, k.max_range)
     before = engine.ctx.pinned.allocations
+    assert before >= 1 and a["point3"].nbytes >= 4 << 20
     del a, fr, views
     b = scene.scan_poses_compact(poses, dirs, k.max_range)
     assert engine.ctx.pinned.allocations == before

@@ -220,6 +220,14 @@ typedef struct lrc_frames {
     uint32_t* index;         /* (K) index of the kept ray inside its pose (the surviving-ray list)   */
     float*    xyzl;          /* (K,4) x, y, z, label bits (sem | ins<<16)                            */
     float*    range_origin;  /* (K) see lrc_compact_io.out_range_origin                              */
+    /* per-pose statistics, (num_poses) each, computed on the device with numpy's own arithmetic (pairwise summation in
+     * 8192-element buffer chunks, every operation in the column's type: csrc/lrc_stats.h), so that they carry the bits
+     * np.mean / np.std give on the same frame -- what the reference's ScanQuality records hold
+     * (s3dis_simulator.py:276-286); 0 for a pose that kept nothing.  The column itself need not be requested. */
+    float*    range_origin_mean;   /* np.mean(np.linalg.norm(points, axis=1)), float32               */
+    float*    range_origin_std;    /* np.std(...)                                                    */
+    double*   incident_mean;       /* np.mean(incident_angles), float64                              */
+    double*   incident_std;        /* np.std(incident_angles)                                        */
 } lrc_frames;
 int lrc_scan_poses_compact(lrc_scene* scene, const double* poses16, uint64_t num_poses,
                            const double* dirs3, uint64_t rays_per_pose, double max_range,

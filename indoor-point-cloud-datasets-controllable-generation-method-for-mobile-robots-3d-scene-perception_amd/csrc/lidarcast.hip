@@ -63,7 +63,7 @@ enum PoolSlot { kPoolRays = 0, kPoolT, kPoolPrim, kPoolNormal, kPoolPoint, kPool
                 kPoolPoses, kPoolDirs, kPoolOffs, kPoolCen, kPoolNoise,
                 // *_compact entry points: scan angles in, per-wave keep counts, compacted frame arrays out
                 kPoolAngles, kPoolKeep, kPoolTile, kPoolCounts, kPoolOutPoint, kPoolOutSem, kPoolOutIns, kPoolOutInc,
-                kPoolOutIdx, kPoolOutXyzl, kPoolOutRange, kPoolStats, kPoolSlots };
+                kPoolOutIdx, kPoolOutXyzl, kPoolOutRange, kPoolStats, kPoolFrameStats, kPoolSlots };
 
 #ifndef LRC_REBUILD_R
 #define LRC_REBUILD_R 2      // tiles (of 64 entries) one wave of the cloud rebuild handles (1, 2, 4, 8 measured equal)
@@ -90,8 +90,8 @@ struct lrc_ctx {
     // *_compact entry points: kernels on one stream, the transfers of finished pose chunks on another
     hipStream_t s_compute = nullptr, s_copy = nullptr;
     hipEvent_t ev_chunk[8] = {};
-    uint64_t* h_counts = nullptr;       // page-locked landing area of the per-pose counts (async copies need one)
-    uint64_t h_counts_cap = 0;
+    uint64_t* h_counts = nullptr;       // page-locked landing area of the per-pose counts and statistics (async copies
+    uint64_t h_counts_cap = 0;          // need one): counts (P u64) | 4 x P doubles of per-pose statistics
 };
 
 struct lrc_scene {
@@ -639,6 +639,7 @@ __global__ __launch_bounds__(kTBlock, W) void trace_refill_kernel(const TracePar
 }
 
 #include "lrc_sector.h"
+#include "lrc_stats.h"
 
 // ---- compaction -------------------------------------------------------------------------------
 // tile = 64 consecutive entries of one segment = one wave; tile index = seg * tps + chunk.
@@ -1650,18 +1651,22 @@ namespace {
 struct FrameStage {
     DevBuf t, p3, sem, ins, inc, tile;                     // fixed-stride records
     DevBuf cnt, op3, osem, oins, oinc, oidx, oxyzl, orng;   // compacted outputs
+    DevBuf fstat;                                           // per-pose statistics: 4 x P doubles
     lrc_hits rec{};
     lrc_compact_io io{};
+    double* d_stats = nullptr;
     int alloc(lrc_ctx* ctx, const lrc_frames& f, uint64_t P, uint64_t n) {
         int rc;
-        const bool want_pt = f.point3 || f.xyzl || f.range_origin;
+        const bool rstats = f.range_origin_mean || f.range_origin_std, istats = f.incident_mean || f.incident_std;
+        const bool want_pt = f.point3 || f.xyzl || f.range_origin || rstats;
         const bool want_sem = f.sem || f.xyzl, want_ins = f.ins || f.xyzl;
         if ((rc = t.get(ctx, kPoolT, n * 4))) return rc;
         rec.t = (float*)t.p;
         if (want_pt) { if ((rc = p3.get(ctx, kPoolPoint, n * 12))) return rc; rec.point3 = (float*)p3.p; }
         if (want_sem) { if ((rc = sem.get(ctx, kPoolSem, n * 2))) return rc; rec.sem = (uint16_t*)sem.p; }
         if (want_ins) { if ((rc = ins.get(ctx, kPoolIns, n * 2))) return rc; rec.ins = (uint16_t*)ins.p; }
-        if (f.incident_deg) { if ((rc = inc.get(ctx, kPoolInc, n * 8))) return rc; rec.incident_deg = (double*)inc.p; }
+        if (f.incident_deg || istats) { if ((rc = inc.get(ctx, kPoolInc, n * 8))) return rc; rec.incident_deg = (double*)inc.p; }
+        if (rstats || istats) { if ((rc = fstat.get(ctx, kPoolFrameStats, P * 8 * 4))) return rc; d_stats = (double*)fstat.p; }
         if ((rc = tile.get(ctx, kPoolTile, ((n + 63) / 64 + 1) * 4))) return rc;
         rec.tile_count = (uint32_t*)tile.p;
         io.t = rec.t; io.point3 = rec.point3; io.sem = rec.sem; io.ins = rec.ins; io.incident_deg = rec.incident_deg;
@@ -1671,10 +1676,10 @@ struct FrameStage {
         if (f.point3) { if ((rc = op3.get(ctx, kPoolOutPoint, n * 12))) return rc; io.out_point3 = (float*)op3.p; }
         if (f.sem) { if ((rc = osem.get(ctx, kPoolOutSem, n * 2))) return rc; io.out_sem = (uint16_t*)osem.p; }
         if (f.ins) { if ((rc = oins.get(ctx, kPoolOutIns, n * 2))) return rc; io.out_ins = (uint16_t*)oins.p; }
-        if (f.incident_deg) { if ((rc = oinc.get(ctx, kPoolOutInc, n * 8))) return rc; io.out_incident_deg = (double*)oinc.p; }
+        if (f.incident_deg || istats) { if ((rc = oinc.get(ctx, kPoolOutInc, n * 8))) return rc; io.out_incident_deg = (double*)oinc.p; }
         if (f.index) { if ((rc = oidx.get(ctx, kPoolOutIdx, n * 4))) return rc; io.out_index = (uint32_t*)oidx.p; }
         if (f.xyzl) { if ((rc = oxyzl.get(ctx, kPoolOutXyzl, n * 16))) return rc; io.out_xyzl = (float*)oxyzl.p; }
-        if (f.range_origin) { if ((rc = orng.get(ctx, kPoolOutRange, n * 4))) return rc; io.out_range_origin = (float*)orng.p; }
+        if (f.range_origin || rstats) { if ((rc = orng.get(ctx, kPoolOutRange, n * 4))) return rc; io.out_range_origin = (float*)orng.p; }
         return LRC_OK;
     }
 };
@@ -1699,7 +1704,7 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
     if (rc) return rc;
     if (ctx->h_counts_cap < P) {
         if (ctx->h_counts) { (void)hipHostFree(ctx->h_counts); ctx->h_counts = nullptr; ctx->h_counts_cap = 0; }
-        LRC_HIP(hipHostMalloc((void**)&ctx->h_counts, (P + P / 4 + 64) * 8, hipHostMallocDefault));
+        LRC_HIP(hipHostMalloc((void**)&ctx->h_counts, (P + P / 4 + 64) * 8 * 5, hipHostMallocDefault));
         ctx->h_counts_cap = P + P / 4 + 64;
     }
     // chunks only pay when there is enough to overlap, and need pose boundaries on 64-ray tiles (fused keep counts)
@@ -1741,6 +1746,26 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
         if (io.out_range_origin) io.out_range_origin = st.io.out_range_origin + r0;
         if ((rc = lrc_compact_dev(ctx, np_, N, &io, ctx->s_compute))) return rc;
         LRC_HIP(hipMemcpyAsync(ctx->h_counts + p0, st.io.counts + p0, np_ * 8, hipMemcpyDeviceToHost, ctx->s_compute));
+        if (st.d_stats) {
+            // per-pose statistics of the compacted columns, numpy's arithmetic (lrc_stats.h): floats in the first two
+            // blocks of P doubles' worth of space, doubles in the last two
+            float* rm = (float*)st.d_stats;            float* rs = (float*)(st.d_stats + P);
+            double* im = st.d_stats + 2 * P;           double* is = st.d_stats + 3 * P;
+            if (out->range_origin_mean || out->range_origin_std)
+                hipLaunchKernelGGL(segment_stats_kernel<float>, dim3((uint32_t)np_), dim3(256), 0, ctx->s_compute,
+                                   (const float*)st.io.out_range_origin, (const uint64_t*)(st.io.counts + p0), r0, np_,
+                                   rm + p0, rs + p0);
+            if (out->incident_mean || out->incident_std)
+                hipLaunchKernelGGL(segment_stats_kernel<double>, dim3((uint32_t)np_), dim3(256), 0, ctx->s_compute,
+                                   (const double*)st.io.out_incident_deg, (const uint64_t*)(st.io.counts + p0), r0, np_,
+                                   im + p0, is + p0);
+            LRC_HIP(hipGetLastError());
+            double* hs = (double*)(ctx->h_counts + ctx->h_counts_cap);
+            LRC_HIP(hipMemcpyAsync((float*)hs + p0, rm + p0, np_ * 4, hipMemcpyDeviceToHost, ctx->s_compute));
+            LRC_HIP(hipMemcpyAsync((float*)(hs + ctx->h_counts_cap) + p0, rs + p0, np_ * 4, hipMemcpyDeviceToHost, ctx->s_compute));
+            LRC_HIP(hipMemcpyAsync(hs + 2 * ctx->h_counts_cap + p0, im + p0, np_ * 8, hipMemcpyDeviceToHost, ctx->s_compute));
+            LRC_HIP(hipMemcpyAsync(hs + 3 * ctx->h_counts_cap + p0, is + p0, np_ * 8, hipMemcpyDeviceToHost, ctx->s_compute));
+        }
         LRC_HIP(hipEventRecord(ctx->ev_chunk[c], ctx->s_compute));
         p0 = p1;
     }
@@ -1752,6 +1777,15 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
         LRC_HIP(hipEventSynchronize(ctx->ev_chunk[c]));
         uint64_t Kc = 0;
         for (uint64_t k = p0; k < p1; ++k) { out->counts[k] = ctx->h_counts[k]; Kc += ctx->h_counts[k]; }
+        if (st.d_stats) {
+            const double* hs = (const double*)(ctx->h_counts + ctx->h_counts_cap);
+            for (uint64_t k = p0; k < p1; ++k) {
+                if (out->range_origin_mean) out->range_origin_mean[k] = ((const float*)hs)[k];
+                if (out->range_origin_std) out->range_origin_std[k] = ((const float*)(hs + ctx->h_counts_cap))[k];
+                if (out->incident_mean) out->incident_mean[k] = hs[2 * ctx->h_counts_cap + k];
+                if (out->incident_std) out->incident_std[k] = hs[3 * ctx->h_counts_cap + k];
+            }
+        }
         if (K + Kc > capacity) status = LRC_ERR_INVALID_ARG;        // keep counting: the caller learns the size needed
         if (status == LRC_OK && Kc) {
             hipStream_t cs = ctx->s_copy;

@@ -1,0 +1,140 @@
+// lrc_stats.h -- per-frame mean and standard deviation exactly as numpy computes them (gfx950 only).
+// Included by lidarcast.hip inside its anonymous namespace.
+//
+// What it replaces: the np.mean / np.std calls over every frame's ranges (and incident angles) in the reference's
+// scan loop (s3dis_simulator.py:276-286) -- after the scan moved to the GPU they were what S3DISSimulator.run_simulation
+// spent its time on (64 frames x 65 k values: 5 of 8 ms).  The statistics are part of the frames a drop-in must
+// reproduce, so the kernel follows numpy's arithmetic operation by operation (numpy 2.2, default buffer size):
+//   np.add.reduce over a contiguous 1-D array of n values of type T (no casting):
+//     the array is consumed in buffer chunks of 8192 elements; chunk sums are added left to right;
+//     a chunk is summed by pairwise_sum (numpy/_core/src/umath/loops_utils.h.src):
+//       n < 8    : res = 0; res += a[i] in order
+//       n <= 128 : r[j] = a[j] (j < 8); r[j] += a[i + j] for i = 8, 16, ... < n - n % 8;
+//                  res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)); res += a[i] for the n % 8 tail
+//       else     : n2 = n / 2; n2 -= n2 % 8; pairwise_sum(a, n2) + pairwise_sum(a + n2, n - n2)
+//   np.mean = sum / n in T;  np.std = sqrt(sum((a - mean)^2) / n), every operation in T, mean = sum / n as above
+// (tests/test_oracle.py checks this restatement against numpy for many lengths; the -m gpu tests check the kernel).
+// A full chunk (8192 = 64 leaves of 128) is a balanced tree and runs in parallel: 8 lanes per leaf carry the eight
+// accumulators, three xor-shuffles combine them in numpy's bracket order (IEEE addition commutes, so which lane of a
+// pair holds which operand is immaterial), six LDS levels combine the leaves.  The trailing partial chunk has an
+// irregular tree: one lane runs the recursion literally with an explicit stack.
+#pragma once
+
+template <typename T, bool SQ>
+__device__ __forceinline__ T stat_term(const T* a, uint64_t i, T mean) {
+    if (!SQ) return a[i];
+    const T x = a[i] - mean;          // two roundings, as numpy's (arr - mean) then x * x (no FMA: -ffp-contract=off)
+    return x * x;
+}
+
+// literal pairwise_sum over a[0..n), n < 8192 + 1, one lane
+template <typename T, bool SQ>
+__device__ T pw_serial(const T* a, uint64_t n, T mean) {
+    struct Fr { uint64_t start, n; int phase; T left; };
+    Fr st[24];
+    int sp = 0;
+    st[0] = Fr{0, n, 0, (T)0};
+    T ret = (T)0;
+    while (sp >= 0) {
+        Fr& f = st[sp];
+        if (f.phase == 0) {
+            if (f.n < 8) {
+                T res = (T)0;
+                for (uint64_t i = 0; i < f.n; ++i) res += stat_term<T, SQ>(a, f.start + i, mean);
+                ret = res; --sp;
+            } else if (f.n <= 128) {
+                T r[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = stat_term<T, SQ>(a, f.start + j, mean);
+                uint64_t i = 8;
+                for (; i < f.n - (f.n % 8); i += 8)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r[j] += stat_term<T, SQ>(a, f.start + i + j, mean);
+                T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                for (; i < f.n; ++i) res += stat_term<T, SQ>(a, f.start + i, mean);
+                ret = res; --sp;
+            } else {
+                uint64_t n2 = f.n / 2;
+                n2 -= n2 % 8;
+                f.phase = 1;
+                st[sp + 1] = Fr{f.start, n2, 0, (T)0};
+                ++sp;
+            }
+        } else if (f.phase == 1) {
+            uint64_t n2 = f.n / 2;
+            n2 -= n2 % 8;
+            f.left = ret;
+            f.phase = 2;
+            st[sp + 1] = Fr{f.start + n2, f.n - n2, 0, (T)0};
+            ++sp;
+        } else {
+            ret = f.left + ret;
+            --sp;
+        }
+    }
+    return ret;
+}
+
+// np.add.reduce(a[0..n)) (or of (a - mean)^2) by one 256-thread workgroup; the result is valid in thread 0
+template <typename T, bool SQ>
+__device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 64 */) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t grp = tid >> 3, j = tid & 7u;       // 32 groups of 8 lanes
+    T total = (T)0;
+    const uint64_t full = n / 8192;
+    for (uint64_t c = 0; c < full; ++c) {
+        const T* ch = a + c * 8192;
+        for (uint32_t leaf = grp; leaf < 64u; leaf += 32u) {
+            const uint64_t b = (uint64_t)leaf * 128u;
+            T r = stat_term<T, SQ>(ch, b + j, mean);
+            for (uint32_t i = 8; i < 128u; i += 8) r += stat_term<T, SQ>(ch, b + i + j, mean);
+            r = r + __shfl_xor(r, 1, 64);
+            r = r + __shfl_xor(r, 2, 64);
+            r = r + __shfl_xor(r, 4, 64);
+            if (j == 0) s_leaf[leaf] = r;
+        }
+        __syncthreads();
+        for (uint32_t w = 32; w >= 1; w >>= 1) {          // balanced tree: node k = left child 2k + right child 2k+1
+            T v = (T)0;
+            if (tid < w) v = s_leaf[2 * tid] + s_leaf[2 * tid + 1];
+            __syncthreads();
+            if (tid < w) s_leaf[tid] = v;
+            __syncthreads();
+        }
+        if (tid == 0) total = c == 0 ? s_leaf[0] : total + s_leaf[0];
+        __syncthreads();
+    }
+    const uint64_t rest = n - full * 8192;
+    if (rest && tid == 0) {
+        const T part = pw_serial<T, SQ>(a + full * 8192, rest, mean);
+        total = full == 0 ? part : total + part;
+    }
+    return total;
+}
+
+// one workgroup per segment (frame): mean and population standard deviation of its values, numpy's way
+template <typename T>
+__global__ __launch_bounds__(256) void segment_stats_kernel(const T* values, const uint64_t* counts, uint64_t first_row,
+                                                            uint64_t num_segments, T* out_mean, T* out_std) {
+    __shared__ T s_leaf[64];
+    __shared__ T s_mean;
+    const uint64_t seg = blockIdx.x;
+    if (seg >= num_segments) return;
+    uint64_t start = first_row;
+    for (uint64_t k = 0; k < seg; ++k) start += counts[k];
+    const uint64_t n = counts[seg];
+    if (n == 0) {
+        if (threadIdx.x == 0) { out_mean[seg] = (T)0; out_std[seg] = (T)0; }
+        return;
+    }
+    const T* a = values + start;
+    const T sum = block_reduce_numpy<T, false>(a, n, (T)0, s_leaf);
+    if (threadIdx.x == 0) s_mean = sum / (T)n;
+    __syncthreads();
+    const T mean = s_mean;
+    const T ss = block_reduce_numpy<T, true>(a, n, mean, s_leaf);
+    if (threadIdx.x == 0) {
+        out_mean[seg] = mean;
+        out_std[seg] = sizeof(T) == 4 ? (T)__builtin_sqrtf((float)(ss / (T)n)) : (T)__builtin_sqrt((double)(ss / (T)n));
+    }
+}

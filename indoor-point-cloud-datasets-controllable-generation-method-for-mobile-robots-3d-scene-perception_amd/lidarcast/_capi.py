@@ -67,7 +67,8 @@ class LrcCompactIO(C.Structure):
 class LrcFrames(C.Structure):
     _fields_ = [("counts", C.c_void_p), ("point3", C.c_void_p), ("sem", C.c_void_p), ("ins", C.c_void_p),
                 ("incident_deg", C.c_void_p), ("index", C.c_void_p), ("xyzl", C.c_void_p),
-                ("range_origin", C.c_void_p)]
+                ("range_origin", C.c_void_p), ("range_origin_mean", C.c_void_p), ("range_origin_std", C.c_void_p),
+                ("incident_mean", C.c_void_p), ("incident_std", C.c_void_p)]
 
 
 class LrcGrid(C.Structure):

@@ -359,7 +359,15 @@ class Scene:
         counts = np.zeros(P, dtype=np.uint64)
         fr.counts = counts.ctypes.data
         bufs = {}
+        self._per_pose = {}
         for a in want:
+            if a in ("range_origin_stats", "incident_stats"):   # per-pose mean / std with numpy's arithmetic, on the device
+                col, dt = ("range_origin", np.float32) if a == "range_origin_stats" else ("incident", np.float64)
+                for kind in ("mean", "std"):
+                    arr = np.zeros(P, dtype=dt)
+                    self._per_pose[f"{col}_{kind}"] = arr
+                    setattr(fr, f"{col}_{kind}", arr.ctypes.data)
+                continue
             if a not in _FRAME_SPEC:
                 raise ValueError(f"unknown frame attribute {a!r}")
             dt, tail = _FRAME_SPEC[a]
@@ -373,9 +381,10 @@ class Scene:
             setattr(fr, a, bufs[a].ctypes.data)
         return fr, counts, bufs, cap
 
-    @staticmethod
-    def _frames_end(counts, bufs, total):
+    def _frames_end(self, counts, bufs, total):
         out = {a: b[:total] for a, b in bufs.items()}
+        out.update(self._per_pose)
+        self._per_pose = {}
         out["counts"] = counts.astype(np.int64)
         out["total"] = int(total)
         return out

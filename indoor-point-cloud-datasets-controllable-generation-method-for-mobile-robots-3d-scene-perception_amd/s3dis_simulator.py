@@ -148,6 +148,22 @@ class S3DISSimulator:
             scan_density=k / room_volume,
             range_mean=np.mean(ranges) if k > 0 else 0, range_std=np.std(ranges) if k > 0 else 0)
 
+    def _quality_from_stats(self, fr, total_points_per_scan, room_volume):
+        """ScanQuality of every frame from the per-pose statistics the device computed with numpy's arithmetic."""
+        out = []
+        zero = np.float64(0.0)
+        for i, k in enumerate(fr["counts"].tolist()):
+            if k == 0:
+                out.append(ScanQuality(coverage_ratio=0.0, num_points=0, incident_angle_mean=0, incident_angle_std=0,
+                                       scan_density=0.0, range_mean=0, range_std=0))
+                continue
+            am = zero if self.bug_compatible else fr["incident_mean"][i]
+            asd = zero if self.bug_compatible else fr["incident_std"][i]
+            out.append(ScanQuality(coverage_ratio=k / total_points_per_scan, num_points=k, incident_angle_mean=am,
+                                   incident_angle_std=asd, scan_density=k / room_volume,
+                                   range_mean=fr["range_origin_mean"][i], range_std=fr["range_origin_std"][i]))
+        return out
+
     def _quality_many(self, points, angles, total_points_per_scan, room_volume, ranges):
         """ScanQuality of every frame; frames are independent, so a small thread pool reduces them side by side."""
         zero_angles = self.bug_compatible      # mean and std of an all-zero block are exactly 0.0: no need to reduce it
@@ -195,7 +211,10 @@ class S3DISSimulator:
         # are not even transferred.  range_origin is |point| from the WORLD origin (reference :283-284), float32,
         # formed on the device exactly as np.linalg.norm(points, axis=1) forms it.
         engine = self.raycast_engine
-        want = ("point3", "sem", "ins", "range_origin") + (() if self.bug_compatible else ("incident_deg",))
+        # the per-frame mean / std of the ScanQuality records come from the device as well, computed with numpy's own
+        # summation order (csrc/lrc_stats.h), so neither the range column nor a host reduction is needed
+        want = ("point3", "sem", "ins", "range_origin_stats") + \
+            (() if self.bug_compatible else ("incident_deg", "incident_stats"))
         batched = isinstance(self.lidar_config, Indoor8LineLidarIntrinsics) and \
             self.lidar_config.vertical_degrees is not None
         device_gen = bool(self.config.get("raycast_engine", {}).get("device_ray_generation", False))
@@ -228,13 +247,15 @@ class S3DISSimulator:
             seg, off = engine.scan_lidars(lidars, mesh, want=("t", "point3", "incident_deg", "sem", "ins"))
         if fr is not None:
             pts_f, sem_f, ins_f = (engine.split_frames(fr, a) for a in ("point3", "sem", "ins"))
-            rng_f = engine.split_frames(fr, "range_origin")
             if self.bug_compatible:            # one zero block, frames take views of it (reference :266-269)
                 fr["incident_deg"] = np.zeros(fr["total"])
             ang_f = engine.split_frames(fr, "incident_deg")
-            # per-frame statistics are numpy reductions over 10^4..10^5 values each; they release the GIL, so the
-            # frames of a long trajectory are reduced side by side (same numpy calls, same values)
-            qual = self._quality_many(pts_f, ang_f, total, volume, rng_f)
+            if "range_origin_mean" in fr:      # statistics from the device
+                qual = self._quality_from_stats(fr, total, volume)
+            else:
+                # (sharded scans) per-frame statistics are numpy reductions over 10^4..10^5 values each; they release
+                # the GIL, so the frames of a long trajectory are reduced side by side (same numpy calls, same values)
+                qual = self._quality_many(pts_f, ang_f, total, volume, engine.split_frames(fr, "range_origin"))
         for i, wp in enumerate(waypoints):
             if fr is not None:
                 sim_scene.append_frame(S3DISSimFrame(i, pts_f[i], ang_f[i], qual[i], semantic_labels=sem_f[i],

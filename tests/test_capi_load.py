@@ -38,7 +38,7 @@ def test_struct_layouts_match_header():
     assert [n for n, _ in LrcCompactIO._fields_] == header_fields("lrc_compact_io")
     assert C.sizeof(LrcCompactIO) == 14 * 8
     assert [n for n, _ in LrcFrames._fields_] == header_fields("lrc_frames")
-    assert C.sizeof(LrcFrames) == 8 * 8
+    assert C.sizeof(LrcFrames) == 12 * 8
     assert C.sizeof(LrcSceneInfo) == 5 * 8 + 2 * 4 + 8 + 2 * 8 + 6 * 4
 
 

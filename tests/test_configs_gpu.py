@@ -515,3 +515,47 @@ def test_packet_kernel_full_size_c3(engine):
     assert fa["total"] == fb["total"] > 4e6 and np.array_equal(fa["counts"], fb["counts"])
     for a in ("point3", "sem", "ins", "index"):
         assert_bit_equal(fa[a], fb[a], a)
+
+
+def test_device_frame_statistics_carry_numpys_bits(engine):
+    """lrc_frames.range_origin_mean/std, incident_mean/std (csrc/lrc_stats.h) against np.mean / np.std of the same
+    frames: equal BITS, for frame sizes on every branch of numpy's summation (a handful of returns, <= 128, several
+    full 8192-element chunks, a ragged tail), float32 and float64; and through S3DISSimulator.run_simulation the
+    ScanQuality records equal what the reference's formulas give on the frames (s3dis_simulator.py:276-286)."""
+    from lidar import Indoor8LineLidarIntrinsics
+    from lidarcast import synth
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=4, seed=5, cell=0.05)
+    sensors = [sensor_small(lines=4, width=64, max_range=1.05),                 # a few returns per pose
+               sensor_small(lines=5, width=200, max_range=1.9),                 # hundreds, ragged
+               Indoor8LineLidarIntrinsics(vertical_res=16, horizontal_res=1024, max_range=30.0,
+                                          vertical_degrees=list(np.linspace(20, -25, 16))),   # 2 full chunks
+               sensor_32x2048()]                                              # 8 full chunks, minus the room's seams
+    seen = set()
+    for k in sensors:
+        poses = np.stack([pose(0.6 + 0.45 * i, 1.2 + 0.1 * i, 1.0, 0.37 * i) for i in range(7)])
+        fr = engine.scan_frames(k, poses, mesh, want=("point3", "incident_deg", "range_origin", "range_origin_stats",
+                                                      "incident_stats"))
+        rng_f, ang_f = engine.split_frames(fr, "range_origin"), engine.split_frames(fr, "incident_deg")
+        for i in range(len(poses)):
+            n = int(fr["counts"][i])
+            seen.add(0 if n == 0 else 1 if n < 8 else 2 if n <= 128 else 3 if n < 8192 else 4)
+            if n == 0:
+                assert fr["range_origin_mean"][i] == 0 and fr["incident_std"][i] == 0
+                continue
+            assert_bit_equal(fr["range_origin_mean"][i:i + 1], np.array([np.mean(rng_f[i])]), f"range mean, n={n}")
+            assert_bit_equal(fr["range_origin_std"][i:i + 1], np.array([np.std(rng_f[i])]), f"range std, n={n}")
+            assert_bit_equal(fr["incident_mean"][i:i + 1], np.array([np.mean(ang_f[i])]), f"incident mean, n={n}")
+            assert_bit_equal(fr["incident_std"][i:i + 1], np.array([np.std(ang_f[i])]), f"incident std, n={n}")
+    assert {2, 3, 4} <= seen or {1, 3, 4} <= seen, seen
+    # through the simulator, not bug-compatible so the incident statistics are live too
+    from s3dis_simulator import S3DISSimulator
+    from trajectory import line_trajectory
+    sim = S3DISSimulator({"raycast_engine": {"use_gpu": True}}, use_dense_lidar=True, bug_compatible=False)
+    sim.raycast_engine = engine
+    sim.load_scene(mesh, "room")
+    sc = sim.run_simulation(line_trajectory((0.8, 1.5, 1.0), (3.2, 1.5, 1.0), 9, yaw=0.3))
+    for f in sc.frames:
+        q, r = f.scan_quality, np.linalg.norm(f.points, axis=1)
+        assert q.num_points == len(f.points) > 1000
+        assert q.range_mean == np.mean(r) and q.range_std == np.std(r) and type(q.range_mean) is np.float32
+        assert q.incident_angle_mean == np.mean(f.incident_angles) and q.incident_angle_std == np.std(f.incident_angles)

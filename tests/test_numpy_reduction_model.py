@@ -1,0 +1,61 @@
+"""CPU: the model of numpy's float reductions that csrc/lrc_stats.h implements on the device (per-frame ScanQuality
+statistics, reference s3dis_simulator.py:276-286) IS what this numpy does: buffer chunks of 8192 elements added left
+to right, each chunk by pairwise_sum (8 accumulators up to 128 elements, halving above), mean = sum / n and
+std = sqrt(sum((a - mean)^2) / n) with every operation in the array's type.  If a numpy upgrade changes the scheme this
+test fails here, before the GPU comparison does."""
+import numpy as np
+import pytest
+
+
+def _pw(a):
+    n, T = len(a), a.dtype.type
+    if n < 8:
+        r = T(0)
+        for x in a:
+            r = T(r + x)
+        return r
+    if n <= 128:
+        body = a[:n - n % 8].reshape(-1, 8)
+        r = body[0].copy()
+        for row in body[1:]:
+            r = (r + row).astype(a.dtype)
+        res = T(T(T(r[0] + r[1]) + T(r[2] + r[3])) + T(T(r[4] + r[5]) + T(r[6] + r[7])))
+        for x in a[n - n % 8:]:
+            res = T(res + x)
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return T(_pw(a[:n2]) + _pw(a[n2:]))
+
+
+def model_sum(a):
+    res = None
+    for i in range(0, len(a), 8192):
+        c = _pw(a[i:i + 8192])
+        res = c if res is None else a.dtype.type(res + c)
+    return res
+
+
+def model_mean_std(a):
+    T = a.dtype.type
+    n = T(len(a))
+    mean = T(model_sum(a) / n)
+    x = (a - mean).astype(a.dtype)
+    x = (x * x).astype(a.dtype)
+    return mean, T(np.sqrt(T(model_sum(x) / n)))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_model_matches_numpy(dtype):
+    rng = np.random.default_rng(3)
+    for n in [1, 5, 7, 8, 9, 63, 127, 128, 129, 255, 1000, 4097, 8191, 8192, 8193, 16384, 20011, 40000, 65530, 65536, 70001]:
+        for _ in range(2):
+            a = (rng.random(n) * 7.5 + 0.3).astype(dtype)
+            assert model_sum(a) == np.add.reduce(a), n
+            m, s = model_mean_std(a)
+            assert m == np.mean(a) and type(np.mean(a)) is dtype, n
+            assert s == np.std(a), n
+    # a slice of a larger array (what a frame is): contiguous, same scheme
+    big = (rng.random(100000) * 5).astype(dtype)
+    v = big[12345:12345 + 33333]
+    assert model_sum(v) == np.add.reduce(v) and model_mean_std(v)[1] == np.std(v)

@@ -17,7 +17,8 @@
 // A full chunk (8192 = 64 leaves of 128) is a balanced tree and runs in parallel: 8 lanes per leaf carry the eight
 // accumulators, three xor-shuffles combine them in numpy's bracket order (IEEE addition commutes, so which lane of a
 // pair holds which operand is immaterial), six LDS levels combine the leaves.  The trailing partial chunk has an
-// irregular tree: one lane runs the recursion literally with an explicit stack.
+// irregular tree (at most 126 leaves of 65..128 elements, or one short leaf): one lane walks the recursion to list the
+// leaves, all lanes sum them, the same lane walks it again to combine the sums in bracket order.
 #pragma once
 
 template <typename T, bool SQ>
@@ -27,42 +28,33 @@ __device__ __forceinline__ T stat_term(const T* a, uint64_t i, T mean) {
     return x * x;
 }
 
-// literal pairwise_sum over a[0..n), n < 8192 + 1, one lane
-template <typename T, bool SQ>
-__device__ T pw_serial(const T* a, uint64_t n, T mean) {
-    struct Fr { uint64_t start, n; int phase; T left; };
-    Fr st[24];
+// The pairwise_sum tree of a chunk of n < 8192 elements, walked by ONE lane without touching the data:
+//   ENUM = true : writes the leaves (start, length <= 128) left to right into s_ls / s_ln, returns their number
+//   ENUM = false: combines the leaf sums s_v[0..) in the tree's bracket order, returns the chunk's sum
+template <typename T, bool ENUM>
+__device__ T pw_walk(uint64_t n, uint32_t* s_ls, uint32_t* s_ln, const T* s_v) {
+    struct Fr { uint32_t start, n; int phase; T left; };
+    Fr st[16];
     int sp = 0;
-    st[0] = Fr{0, n, 0, (T)0};
+    uint32_t leaf = 0;
+    st[0] = Fr{0u, (uint32_t)n, 0, (T)0};
     T ret = (T)0;
     while (sp >= 0) {
         Fr& f = st[sp];
         if (f.phase == 0) {
-            if (f.n < 8) {
-                T res = (T)0;
-                for (uint64_t i = 0; i < f.n; ++i) res += stat_term<T, SQ>(a, f.start + i, mean);
-                ret = res; --sp;
-            } else if (f.n <= 128) {
-                T r[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) r[j] = stat_term<T, SQ>(a, f.start + j, mean);
-                uint64_t i = 8;
-                for (; i < f.n - (f.n % 8); i += 8)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) r[j] += stat_term<T, SQ>(a, f.start + i + j, mean);
-                T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-                for (; i < f.n; ++i) res += stat_term<T, SQ>(a, f.start + i, mean);
-                ret = res; --sp;
+            if (f.n <= 128u) {
+                if (ENUM) { s_ls[leaf] = f.start; s_ln[leaf] = f.n; } else ret = s_v[leaf];
+                ++leaf; --sp;
             } else {
-                uint64_t n2 = f.n / 2;
-                n2 -= n2 % 8;
+                uint32_t n2 = f.n / 2u;
+                n2 -= n2 % 8u;
                 f.phase = 1;
                 st[sp + 1] = Fr{f.start, n2, 0, (T)0};
                 ++sp;
             }
         } else if (f.phase == 1) {
-            uint64_t n2 = f.n / 2;
-            n2 -= n2 % 8;
+            uint32_t n2 = f.n / 2u;
+            n2 -= n2 % 8u;
             f.left = ret;
             f.phase = 2;
             st[sp + 1] = Fr{f.start + n2, f.n - n2, 0, (T)0};
@@ -72,12 +64,30 @@ __device__ T pw_serial(const T* a, uint64_t n, T mean) {
             --sp;
         }
     }
-    return ret;
+    return ENUM ? (T)leaf : ret;
+}
+
+// one leaf (n <= 128) by 8 lanes: numpy's 8 accumulators, bracketed combine, sequential tail; valid in lane j == 0
+template <typename T, bool SQ>
+__device__ __forceinline__ T leaf_sum8(const T* a, uint32_t n, uint32_t j, T mean) {
+    if (n < 8u) {                                   // res = 0; res += a[i]
+        T res = (T)0;
+        for (uint32_t i = 0; i < n; ++i) res += stat_term<T, SQ>(a, i, mean);
+        return res;
+    }
+    const uint32_t body = n - (n % 8u);
+    T r = stat_term<T, SQ>(a, j, mean);
+    for (uint32_t i = 8; i < body; i += 8) r += stat_term<T, SQ>(a, i + j, mean);
+    r = r + __shfl_xor(r, 1, 64);
+    r = r + __shfl_xor(r, 2, 64);
+    r = r + __shfl_xor(r, 4, 64);
+    for (uint32_t i = body; i < n; ++i) r += stat_term<T, SQ>(a, i, mean);      // every lane adds the same tail
+    return r;
 }
 
 // np.add.reduce(a[0..n)) (or of (a - mean)^2) by one 256-thread workgroup; the result is valid in thread 0
 template <typename T, bool SQ>
-__device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 64 */) {
+__device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 128 */, uint32_t* s_ls, uint32_t* s_ln) {
     const uint32_t tid = threadIdx.x;
     const uint32_t grp = tid >> 3, j = tid & 7u;       // 32 groups of 8 lanes
     T total = (T)0;
@@ -85,12 +95,7 @@ __device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 64 
     for (uint64_t c = 0; c < full; ++c) {
         const T* ch = a + c * 8192;
         for (uint32_t leaf = grp; leaf < 64u; leaf += 32u) {
-            const uint64_t b = (uint64_t)leaf * 128u;
-            T r = stat_term<T, SQ>(ch, b + j, mean);
-            for (uint32_t i = 8; i < 128u; i += 8) r += stat_term<T, SQ>(ch, b + i + j, mean);
-            r = r + __shfl_xor(r, 1, 64);
-            r = r + __shfl_xor(r, 2, 64);
-            r = r + __shfl_xor(r, 4, 64);
+            const T r = leaf_sum8<T, SQ>(ch + (uint64_t)leaf * 128u, 128u, j, mean);
             if (j == 0) s_leaf[leaf] = r;
         }
         __syncthreads();
@@ -104,10 +109,25 @@ __device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 64 
         if (tid == 0) total = c == 0 ? s_leaf[0] : total + s_leaf[0];
         __syncthreads();
     }
-    const uint64_t rest = n - full * 8192;
-    if (rest && tid == 0) {
-        const T part = pw_serial<T, SQ>(a + full * 8192, rest, mean);
-        total = full == 0 ? part : total + part;
+    const uint32_t rest = (uint32_t)(n - full * 8192);
+    if (rest) {                                           // the ragged tail chunk: irregular tree, leaves in parallel
+        __shared__ uint32_t s_nleaf;
+        if (tid == 0) s_nleaf = (uint32_t)pw_walk<T, true>(rest, s_ls, s_ln, s_leaf);
+        __syncthreads();
+        const uint32_t nleaf = s_nleaf;
+        const T* ch = a + full * 8192;
+        T mine[4] = {(T)0, (T)0, (T)0, (T)0};
+        for (uint32_t leaf = grp, k = 0; leaf < nleaf; leaf += 32u, ++k)
+            mine[k] = leaf_sum8<T, SQ>(ch + s_ls[leaf], s_ln[leaf], j, mean);
+        __syncthreads();                                  // s_leaf is free again (pw_walk<ENUM> did not use it)
+        for (uint32_t leaf = grp, k = 0; leaf < nleaf; leaf += 32u, ++k)
+            if (j == 0) s_leaf[leaf] = mine[k];
+        __syncthreads();
+        if (tid == 0) {
+            const T part = pw_walk<T, false>(rest, s_ls, s_ln, s_leaf);
+            total = full == 0 ? part : total + part;
+        }
+        __syncthreads();
     }
     return total;
 }
@@ -116,7 +136,8 @@ __device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 64 
 template <typename T>
 __global__ __launch_bounds__(256) void segment_stats_kernel(const T* values, const uint64_t* counts, uint64_t first_row,
                                                             uint64_t num_segments, T* out_mean, T* out_std) {
-    __shared__ T s_leaf[64];
+    __shared__ T s_leaf[128];
+    __shared__ uint32_t s_ls[128], s_ln[128];
     __shared__ T s_mean;
     const uint64_t seg = blockIdx.x;
     if (seg >= num_segments) return;
@@ -128,11 +149,11 @@ __global__ __launch_bounds__(256) void segment_stats_kernel(const T* values, con
         return;
     }
     const T* a = values + start;
-    const T sum = block_reduce_numpy<T, false>(a, n, (T)0, s_leaf);
+    const T sum = block_reduce_numpy<T, false>(a, n, (T)0, s_leaf, s_ls, s_ln);
     if (threadIdx.x == 0) s_mean = sum / (T)n;
     __syncthreads();
     const T mean = s_mean;
-    const T ss = block_reduce_numpy<T, true>(a, n, mean, s_leaf);
+    const T ss = block_reduce_numpy<T, true>(a, n, mean, s_leaf, s_ls, s_ln);
     if (threadIdx.x == 0) {
         out_mean[seg] = mean;
         out_std[seg] = sizeof(T) == 4 ? (T)__builtin_sqrtf((float)(ss / (T)n)) : (T)__builtin_sqrt((double)(ss / (T)n));

@@ -67,7 +67,9 @@ __device__ T pw_walk(uint64_t n, uint32_t* s_ls, uint32_t* s_ln, const T* s_v) {
     return ENUM ? (T)leaf : ret;
 }
 
-// one leaf (n <= 128) by 8 lanes: numpy's 8 accumulators, bracketed combine, sequential tail; valid in lane j == 0
+// one leaf (n <= 128) by 8 lanes: numpy's 8 accumulators, bracketed combine, sequential tail; valid in every lane of
+// the group.  All of the leaf's rows are fetched before the first add (the adds are a dependent chain, the loads need
+// not be), rows beyond the leaf are neither fetched nor added.
 template <typename T, bool SQ>
 __device__ __forceinline__ T leaf_sum8(const T* a, uint32_t n, uint32_t j, T mean) {
     if (n < 8u) {                                   // res = 0; res += a[i]
@@ -75,38 +77,49 @@ __device__ __forceinline__ T leaf_sum8(const T* a, uint32_t n, uint32_t j, T mea
         for (uint32_t i = 0; i < n; ++i) res += stat_term<T, SQ>(a, i, mean);
         return res;
     }
-    const uint32_t body = n - (n % 8u);
-    T r = stat_term<T, SQ>(a, j, mean);
-    for (uint32_t i = 8; i < body; i += 8) r += stat_term<T, SQ>(a, i + j, mean);
+    const uint32_t rows = n / 8u;                   // 1..16 full rows of 8
+    T v[16];
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k) v[k] = k < rows ? stat_term<T, SQ>(a, k * 8u + j, mean) : (T)0;
+    T r = v[0];
+#pragma unroll
+    for (uint32_t k = 1; k < 16u; ++k)
+        if (k < rows) r += v[k];
     r = r + __shfl_xor(r, 1, 64);
     r = r + __shfl_xor(r, 2, 64);
     r = r + __shfl_xor(r, 4, 64);
-    for (uint32_t i = body; i < n; ++i) r += stat_term<T, SQ>(a, i, mean);      // every lane adds the same tail
+    for (uint32_t i = rows * 8u; i < n; ++i) r += stat_term<T, SQ>(a, i, mean);      // every lane adds the same tail
     return r;
 }
 
+constexpr uint32_t kStatBatch = 8;       // full 8192-element chunks whose leaves are summed side by side
+
 // np.add.reduce(a[0..n)) (or of (a - mean)^2) by one 256-thread workgroup; the result is valid in thread 0
 template <typename T, bool SQ>
-__device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 128 */, uint32_t* s_ls, uint32_t* s_ln) {
+__device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 64 * kStatBatch */, uint32_t* s_ls,
+                                uint32_t* s_ln) {
     const uint32_t tid = threadIdx.x;
     const uint32_t grp = tid >> 3, j = tid & 7u;       // 32 groups of 8 lanes
     T total = (T)0;
     const uint64_t full = n / 8192;
-    for (uint64_t c = 0; c < full; ++c) {
-        const T* ch = a + c * 8192;
-        for (uint32_t leaf = grp; leaf < 64u; leaf += 32u) {
+    for (uint64_t c0 = 0; c0 < full; c0 += kStatBatch) {
+        const uint32_t nb = (uint32_t)(full - c0 < kStatBatch ? full - c0 : kStatBatch);
+        const T* ch = a + c0 * 8192;
+        for (uint32_t leaf = grp; leaf < nb * 64u; leaf += 32u) {          // leaves of all chunks of the batch
             const T r = leaf_sum8<T, SQ>(ch + (uint64_t)leaf * 128u, 128u, j, mean);
             if (j == 0) s_leaf[leaf] = r;
         }
         __syncthreads();
-        for (uint32_t w = 32; w >= 1; w >>= 1) {          // balanced tree: node k = left child 2k + right child 2k+1
+        for (uint32_t w = 32; w >= 1; w >>= 1) {          // per chunk a balanced tree: node k = children 2k, 2k + 1
+            const uint32_t chunk = tid / w, k = tid - chunk * w;
             T v = (T)0;
-            if (tid < w) v = s_leaf[2 * tid] + s_leaf[2 * tid + 1];
+            if (chunk < nb) v = s_leaf[chunk * 64u + 2u * k] + s_leaf[chunk * 64u + 2u * k + 1u];
             __syncthreads();
-            if (tid < w) s_leaf[tid] = v;
+            if (chunk < nb) s_leaf[chunk * 64u + k] = v;
             __syncthreads();
         }
-        if (tid == 0) total = c == 0 ? s_leaf[0] : total + s_leaf[0];
+        if (tid == 0)
+            for (uint32_t c = 0; c < nb; ++c) total = (c0 + c == 0) ? s_leaf[c * 64u] : total + s_leaf[c * 64u];
         __syncthreads();
     }
     const uint32_t rest = (uint32_t)(n - full * 8192);
@@ -116,12 +129,10 @@ __device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 128
         __syncthreads();
         const uint32_t nleaf = s_nleaf;
         const T* ch = a + full * 8192;
-        T mine[4] = {(T)0, (T)0, (T)0, (T)0};
-        for (uint32_t leaf = grp, k = 0; leaf < nleaf; leaf += 32u, ++k)
-            mine[k] = leaf_sum8<T, SQ>(ch + s_ls[leaf], s_ln[leaf], j, mean);
-        __syncthreads();                                  // s_leaf is free again (pw_walk<ENUM> did not use it)
-        for (uint32_t leaf = grp, k = 0; leaf < nleaf; leaf += 32u, ++k)
-            if (j == 0) s_leaf[leaf] = mine[k];
+        for (uint32_t leaf = grp; leaf < nleaf; leaf += 32u) {
+            const T r = leaf_sum8<T, SQ>(ch + s_ls[leaf], s_ln[leaf], j, mean);
+            if (j == 0) s_leaf[leaf] = r;
+        }
         __syncthreads();
         if (tid == 0) {
             const T part = pw_walk<T, false>(rest, s_ls, s_ln, s_leaf);
@@ -136,7 +147,7 @@ __device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 128
 template <typename T>
 __global__ __launch_bounds__(256) void segment_stats_kernel(const T* values, const uint64_t* counts, uint64_t first_row,
                                                             uint64_t num_segments, T* out_mean, T* out_std) {
-    __shared__ T s_leaf[128];
+    __shared__ T s_leaf[64 * kStatBatch];
     __shared__ uint32_t s_ls[128], s_ln[128];
     __shared__ T s_mean;
     const uint64_t seg = blockIdx.x;

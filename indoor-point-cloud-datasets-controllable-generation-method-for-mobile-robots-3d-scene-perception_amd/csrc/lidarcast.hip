@@ -88,8 +88,8 @@ struct lrc_ctx {
     };
     TileScratch compact_scratch, cloud_scratch;
     // *_compact entry points: kernels on one stream, the transfers of finished pose chunks on another
-    hipStream_t s_compute = nullptr, s_copy = nullptr;
-    hipEvent_t ev_chunk[8] = {};
+    hipStream_t s_compute = nullptr, s_copy = nullptr, s_stats = nullptr;
+    hipEvent_t ev_chunk[8] = {}, ev_compact[8] = {};
     uint64_t* h_counts = nullptr;       // page-locked landing area of the per-pose counts and statistics (async copies
     uint64_t h_counts_cap = 0;          // need one): counts (P u64) | 4 x P doubles of per-pose statistics
 };
@@ -905,7 +905,9 @@ int lrc_ctx_destroy(lrc_ctx* ctx) {
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->s_compute) (void)hipStreamDestroy(ctx->s_compute);
     if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
+    if (ctx->s_stats) (void)hipStreamDestroy(ctx->s_stats);
     for (hipEvent_t e : ctx->ev_chunk) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_compact) if (e) (void)hipEventDestroy(e);
     for (lrc_ctx::TileScratch* sc : {&ctx->compact_scratch, &ctx->cloud_scratch}) {
         if (sc->d_tile_off) (void)hipFree(sc->d_tile_off);
         if (sc->d_tile_cnt) (void)hipFree(sc->d_tile_cnt);
@@ -1687,7 +1689,10 @@ struct FrameStage {
 int ensure_streams(lrc_ctx* ctx) {
     if (!ctx->s_compute) LRC_HIP(hipStreamCreateWithFlags(&ctx->s_compute, hipStreamNonBlocking));
     if (!ctx->s_copy) LRC_HIP(hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
+    if (!ctx->s_stats) LRC_HIP(hipStreamCreateWithFlags(&ctx->s_stats, hipStreamNonBlocking));
     for (hipEvent_t& e : ctx->ev_chunk)
+        if (!e) LRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t& e : ctx->ev_compact)
         if (!e) LRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return LRC_OK;
 }
@@ -1746,27 +1751,32 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
         if (io.out_range_origin) io.out_range_origin = st.io.out_range_origin + r0;
         if ((rc = lrc_compact_dev(ctx, np_, N, &io, ctx->s_compute))) return rc;
         LRC_HIP(hipMemcpyAsync(ctx->h_counts + p0, st.io.counts + p0, np_ * 8, hipMemcpyDeviceToHost, ctx->s_compute));
+        LRC_HIP(hipEventRecord(ctx->ev_chunk[c], ctx->s_compute));
         if (st.d_stats) {
-            // per-pose statistics of the compacted columns, numpy's arithmetic (lrc_stats.h): floats in the first two
-            // blocks of P doubles' worth of space, doubles in the last two
+            // per-pose statistics of the compacted columns, numpy's arithmetic (lrc_stats.h), on a stream of their own:
+            // they need this chunk's compaction and nothing else, so they run beside the next chunk's trace and the
+            // row transfers.  Floats in the first two blocks of P doubles' worth of space, doubles in the last two.
+            hipStream_t ss = ctx->s_stats;
+            LRC_HIP(hipStreamWaitEvent(ss, ctx->ev_chunk[c], 0));
             float* rm = (float*)st.d_stats;            float* rs = (float*)(st.d_stats + P);
             double* im = st.d_stats + 2 * P;           double* is = st.d_stats + 3 * P;
-            if (out->range_origin_mean || out->range_origin_std)
-                hipLaunchKernelGGL(segment_stats_kernel<float>, dim3((uint32_t)np_), dim3(256), 0, ctx->s_compute,
+            double* hs = (double*)(ctx->h_counts + ctx->h_counts_cap);
+            if (out->range_origin_mean || out->range_origin_std) {
+                hipLaunchKernelGGL(segment_stats_kernel<float>, dim3((uint32_t)np_), dim3(256), 0, ss,
                                    (const float*)st.io.out_range_origin, (const uint64_t*)(st.io.counts + p0), r0, np_,
                                    rm + p0, rs + p0);
-            if (out->incident_mean || out->incident_std)
-                hipLaunchKernelGGL(segment_stats_kernel<double>, dim3((uint32_t)np_), dim3(256), 0, ctx->s_compute,
+                LRC_HIP(hipMemcpyAsync((float*)hs + p0, rm + p0, np_ * 4, hipMemcpyDeviceToHost, ss));
+                LRC_HIP(hipMemcpyAsync((float*)(hs + ctx->h_counts_cap) + p0, rs + p0, np_ * 4, hipMemcpyDeviceToHost, ss));
+            }
+            if (out->incident_mean || out->incident_std) {
+                hipLaunchKernelGGL(segment_stats_kernel<double>, dim3((uint32_t)np_), dim3(256), 0, ss,
                                    (const double*)st.io.out_incident_deg, (const uint64_t*)(st.io.counts + p0), r0, np_,
                                    im + p0, is + p0);
+                LRC_HIP(hipMemcpyAsync(hs + 2 * ctx->h_counts_cap + p0, im + p0, np_ * 8, hipMemcpyDeviceToHost, ss));
+                LRC_HIP(hipMemcpyAsync(hs + 3 * ctx->h_counts_cap + p0, is + p0, np_ * 8, hipMemcpyDeviceToHost, ss));
+            }
             LRC_HIP(hipGetLastError());
-            double* hs = (double*)(ctx->h_counts + ctx->h_counts_cap);
-            LRC_HIP(hipMemcpyAsync((float*)hs + p0, rm + p0, np_ * 4, hipMemcpyDeviceToHost, ctx->s_compute));
-            LRC_HIP(hipMemcpyAsync((float*)(hs + ctx->h_counts_cap) + p0, rs + p0, np_ * 4, hipMemcpyDeviceToHost, ctx->s_compute));
-            LRC_HIP(hipMemcpyAsync(hs + 2 * ctx->h_counts_cap + p0, im + p0, np_ * 8, hipMemcpyDeviceToHost, ctx->s_compute));
-            LRC_HIP(hipMemcpyAsync(hs + 3 * ctx->h_counts_cap + p0, is + p0, np_ * 8, hipMemcpyDeviceToHost, ctx->s_compute));
         }
-        LRC_HIP(hipEventRecord(ctx->ev_chunk[c], ctx->s_compute));
         p0 = p1;
     }
     uint64_t K = 0;
@@ -1777,15 +1787,6 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
         LRC_HIP(hipEventSynchronize(ctx->ev_chunk[c]));
         uint64_t Kc = 0;
         for (uint64_t k = p0; k < p1; ++k) { out->counts[k] = ctx->h_counts[k]; Kc += ctx->h_counts[k]; }
-        if (st.d_stats) {
-            const double* hs = (const double*)(ctx->h_counts + ctx->h_counts_cap);
-            for (uint64_t k = p0; k < p1; ++k) {
-                if (out->range_origin_mean) out->range_origin_mean[k] = ((const float*)hs)[k];
-                if (out->range_origin_std) out->range_origin_std[k] = ((const float*)(hs + ctx->h_counts_cap))[k];
-                if (out->incident_mean) out->incident_mean[k] = hs[2 * ctx->h_counts_cap + k];
-                if (out->incident_std) out->incident_std[k] = hs[3 * ctx->h_counts_cap + k];
-            }
-        }
         if (K + Kc > capacity) status = LRC_ERR_INVALID_ARG;        // keep counting: the caller learns the size needed
         if (status == LRC_OK && Kc) {
             hipStream_t cs = ctx->s_copy;
@@ -1804,6 +1805,16 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
     }
     LRC_HIP(hipStreamSynchronize(ctx->s_copy));
     LRC_HIP(hipStreamSynchronize(ctx->s_compute));
+    if (st.d_stats) {
+        LRC_HIP(hipStreamSynchronize(ctx->s_stats));
+        const double* hs = (const double*)(ctx->h_counts + ctx->h_counts_cap);
+        for (uint64_t k = 0; k < P; ++k) {
+            if (out->range_origin_mean) out->range_origin_mean[k] = ((const float*)hs)[k];
+            if (out->range_origin_std) out->range_origin_std[k] = ((const float*)(hs + ctx->h_counts_cap))[k];
+            if (out->incident_mean) out->incident_mean[k] = hs[2 * ctx->h_counts_cap + k];
+            if (out->incident_std) out->incident_std[k] = hs[3 * ctx->h_counts_cap + k];
+        }
+    }
     if (out_total) *out_total = K;
     if (status != LRC_OK)
         return fail(LRC_ERR_INVALID_ARG, "frame buffers too small: capacity " + std::to_string(capacity) +

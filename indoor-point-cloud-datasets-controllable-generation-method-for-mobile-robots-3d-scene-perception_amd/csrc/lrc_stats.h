@@ -17,8 +17,8 @@
 // A full chunk (8192 = 64 leaves of 128) is a balanced tree and runs in parallel: 8 lanes per leaf carry the eight
 // accumulators, three xor-shuffles combine them in numpy's bracket order (IEEE addition commutes, so which lane of a
 // pair holds which operand is immaterial), six LDS levels combine the leaves.  The trailing partial chunk has an
-// irregular tree (at most 126 leaves of 65..128 elements, or one short leaf): one lane walks the recursion to list the
-// leaves, all lanes sum them, the same lane walks it again to combine the sums in bracket order.
+// irregular tree, but all its leaves sit on two adjacent depths, so its nodes at the shallower of the two are reached
+// by index arithmetic alone and reduce as a balanced tree again (block_reduce_numpy).
 #pragma once
 
 template <typename T, bool SQ>
@@ -26,45 +26,6 @@ __device__ __forceinline__ T stat_term(const T* a, uint64_t i, T mean) {
     if (!SQ) return a[i];
     const T x = a[i] - mean;          // two roundings, as numpy's (arr - mean) then x * x (no FMA: -ffp-contract=off)
     return x * x;
-}
-
-// The pairwise_sum tree of a chunk of n < 8192 elements, walked by ONE lane without touching the data:
-//   ENUM = true : writes the leaves (start, length <= 128) left to right into s_ls / s_ln, returns their number
-//   ENUM = false: combines the leaf sums s_v[0..) in the tree's bracket order, returns the chunk's sum
-template <typename T, bool ENUM>
-__device__ T pw_walk(uint64_t n, uint32_t* s_ls, uint32_t* s_ln, const T* s_v) {
-    struct Fr { uint32_t start, n; int phase; T left; };
-    Fr st[16];
-    int sp = 0;
-    uint32_t leaf = 0;
-    st[0] = Fr{0u, (uint32_t)n, 0, (T)0};
-    T ret = (T)0;
-    while (sp >= 0) {
-        Fr& f = st[sp];
-        if (f.phase == 0) {
-            if (f.n <= 128u) {
-                if (ENUM) { s_ls[leaf] = f.start; s_ln[leaf] = f.n; } else ret = s_v[leaf];
-                ++leaf; --sp;
-            } else {
-                uint32_t n2 = f.n / 2u;
-                n2 -= n2 % 8u;
-                f.phase = 1;
-                st[sp + 1] = Fr{f.start, n2, 0, (T)0};
-                ++sp;
-            }
-        } else if (f.phase == 1) {
-            uint32_t n2 = f.n / 2u;
-            n2 -= n2 % 8u;
-            f.left = ret;
-            f.phase = 2;
-            st[sp + 1] = Fr{f.start + n2, f.n - n2, 0, (T)0};
-            ++sp;
-        } else {
-            ret = f.left + ret;
-            --sp;
-        }
-    }
-    return ENUM ? (T)leaf : ret;
 }
 
 // one leaf (n <= 128) by 8 lanes: numpy's 8 accumulators, bracketed combine, sequential tail; valid in every lane of
@@ -96,8 +57,7 @@ constexpr uint32_t kStatBatch = 8;       // full 8192-element chunks whose leave
 
 // np.add.reduce(a[0..n)) (or of (a - mean)^2) by one 256-thread workgroup; the result is valid in thread 0
 template <typename T, bool SQ>
-__device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 64 * kStatBatch */, uint32_t* s_ls,
-                                uint32_t* s_ln) {
+__device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 64 * kStatBatch */) {
     const uint32_t tid = threadIdx.x;
     const uint32_t grp = tid >> 3, j = tid & 7u;       // 32 groups of 8 lanes
     T total = (T)0;
@@ -123,22 +83,48 @@ __device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 64 
         __syncthreads();
     }
     const uint32_t rest = (uint32_t)(n - full * 8192);
-    if (rest) {                                           // the ragged tail chunk: irregular tree, leaves in parallel
-        __shared__ uint32_t s_nleaf;
-        if (tid == 0) s_nleaf = (uint32_t)pw_walk<T, true>(rest, s_ls, s_ln, s_leaf);
-        __syncthreads();
-        const uint32_t nleaf = s_nleaf;
+    if (rest) {
+        // The ragged tail chunk.  pairwise_sum halves (n2 = n/2 - (n/2) % 8) until a piece has <= 128 elements; sibling
+        // sizes differ by < 16, so all leaves sit on two adjacent depths D-1 and D and the tree is complete down to depth
+        // E = D - 1 (verified against the literal recursion for every length 1..8191, tests/test_numpy_reduction_model.py).
+        // Slot s of the 2^E nodes at depth E is reached by following the bits of s from the root -- registers only --
+        // and is either a leaf or the sum of its two leaf children; the 2^E values then reduce as a balanced tree.
         const T* ch = a + full * 8192;
-        for (uint32_t leaf = grp; leaf < nleaf; leaf += 32u) {
-            const T r = leaf_sum8<T, SQ>(ch + s_ls[leaf], s_ln[leaf], j, mean);
-            if (j == 0) s_leaf[leaf] = r;
+        T part = (T)0;
+        if (rest <= 128u) {
+            part = leaf_sum8<T, SQ>(ch, rest, j, mean);         // every thread computes it; thread 0's copy is used
+        } else {
+            uint32_t size = rest, D = 0;
+            while (size > 128u) { uint32_t h = size / 2u; h -= h % 8u; size -= h; ++D; }      // follow the larger child
+            const uint32_t E = D - 1u, S = 1u << E;                                            // S <= 64
+            for (uint32_t slot = grp; slot < S; slot += 32u) {
+                uint32_t st = 0, m = rest;
+                for (uint32_t lvl = 0; lvl < E; ++lvl) {
+                    uint32_t h = m / 2u; h -= h % 8u;
+                    if ((slot >> (E - 1u - lvl)) & 1u) { st += h; m -= h; } else m = h;
+                }
+                T v;
+                if (m <= 128u) v = leaf_sum8<T, SQ>(ch + st, m, j, mean);
+                else {
+                    uint32_t h = m / 2u; h -= h % 8u;
+                    const T l = leaf_sum8<T, SQ>(ch + st, h, j, mean);
+                    const T r = leaf_sum8<T, SQ>(ch + st + h, m - h, j, mean);
+                    v = l + r;
+                }
+                if (j == 0) s_leaf[slot] = v;
+            }
+            __syncthreads();
+            for (uint32_t w = S >> 1; w >= 1; w >>= 1) {
+                T v = (T)0;
+                if (tid < w) v = s_leaf[2u * tid] + s_leaf[2u * tid + 1u];
+                __syncthreads();
+                if (tid < w) s_leaf[tid] = v;
+                __syncthreads();
+            }
+            part = s_leaf[0];
+            __syncthreads();
         }
-        __syncthreads();
-        if (tid == 0) {
-            const T part = pw_walk<T, false>(rest, s_ls, s_ln, s_leaf);
-            total = full == 0 ? part : total + part;
-        }
-        __syncthreads();
+        if (tid == 0) total = full == 0 ? part : total + part;
     }
     return total;
 }
@@ -148,7 +134,6 @@ template <typename T>
 __global__ __launch_bounds__(256) void segment_stats_kernel(const T* values, const uint64_t* counts, uint64_t first_row,
                                                             uint64_t num_segments, T* out_mean, T* out_std) {
     __shared__ T s_leaf[64 * kStatBatch];
-    __shared__ uint32_t s_ls[128], s_ln[128];
     __shared__ T s_mean;
     const uint64_t seg = blockIdx.x;
     if (seg >= num_segments) return;
@@ -160,11 +145,11 @@ __global__ __launch_bounds__(256) void segment_stats_kernel(const T* values, con
         return;
     }
     const T* a = values + start;
-    const T sum = block_reduce_numpy<T, false>(a, n, (T)0, s_leaf, s_ls, s_ln);
+    const T sum = block_reduce_numpy<T, false>(a, n, (T)0, s_leaf);
     if (threadIdx.x == 0) s_mean = sum / (T)n;
     __syncthreads();
     const T mean = s_mean;
-    const T ss = block_reduce_numpy<T, true>(a, n, mean, s_leaf, s_ls, s_ln);
+    const T ss = block_reduce_numpy<T, true>(a, n, mean, s_leaf);
     if (threadIdx.x == 0) {
         out_mean[seg] = mean;
         out_std[seg] = sizeof(T) == 4 ? (T)__builtin_sqrtf((float)(ss / (T)n)) : (T)__builtin_sqrt((double)(ss / (T)n));

@@ -59,3 +59,49 @@ def test_model_matches_numpy(dtype):
     big = (rng.random(100000) * 5).astype(dtype)
     v = big[12345:12345 + 33333]
     assert model_sum(v) == np.add.reduce(v) and model_mean_std(v)[1] == np.std(v)
+
+
+def test_ragged_chunk_slot_scheme_equals_the_recursion():
+    """csrc/lrc_stats.h sums the ragged tail chunk without walking pairwise_sum's recursion: it claims that all leaves
+    sit on two adjacent depths, reaches the 2^E nodes of the shallower one by index arithmetic and reduces them as a
+    balanced tree.  Exhaustive check of that claim: for EVERY tail length 1..8191 the bracket structure it produces is the
+    recursion's."""
+    def literal(n, start=0):
+        if n <= 128:
+            return (start, n)
+        h = n // 2
+        h -= h % 8
+        return (literal(h, start), literal(n - h, start + h))
+
+    def slots(n):
+        if n <= 128:
+            return (0, n)
+        size, depth = n, 0
+        while size > 128:
+            h = size // 2
+            h -= h % 8
+            size -= h
+            depth += 1
+        e = depth - 1
+        vals = []
+        for s in range(1 << e):
+            st, m = 0, n
+            for lvl in range(e):
+                h = m // 2
+                h -= h % 8
+                if (s >> (e - 1 - lvl)) & 1:
+                    st, m = st + h, m - h
+                else:
+                    m = h
+            if m <= 128:
+                vals.append((st, m))
+            else:
+                h = m // 2
+                h -= h % 8
+                assert h <= 128 and m - h <= 128
+                vals.append(((st, h), (st + h, m - h)))
+        assert len(vals) <= 64
+        while len(vals) > 1:
+            vals = [(vals[i], vals[i + 1]) for i in range(0, len(vals), 2)]
+        return vals[0]
+    assert all(slots(n) == literal(n) for n in range(1, 8192))

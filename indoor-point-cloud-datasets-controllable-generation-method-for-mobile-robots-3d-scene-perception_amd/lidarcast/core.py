@@ -50,11 +50,13 @@ class PinnedPool:
     100 MB) each time, and frames a caller still holds are never overwritten.
     """
 
-    def __init__(self, ctx, max_free_bytes=1 << 30):
+    def __init__(self, ctx, max_free_bytes=1 << 30, max_outstanding_bytes=4 << 30):
         self._ctx = ctx
         self._free = {}            # size class -> [ptr, ...]
         self._free_bytes = 0
         self._max_free = int(max_free_bytes)
+        self._max_out = int(max_outstanding_bytes)   # page-locked bytes callers may hold at once; beyond it take()
+        self.outstanding = 0                          # hands out ordinary (pageable) memory instead of locking more
         self.allocations = 0       # hipHostMalloc calls so far (tests / bench bookkeeping)
 
     @staticmethod
@@ -68,6 +70,9 @@ class PinnedPool:
         import weakref
         k = self._klass(max(int(nbytes), 1))
         lst = self._free.get(k)
+        if not lst and self.outstanding + k > self._max_out:
+            return np.empty(k, dtype=np.uint8)      # a caller hoarding frames: stop locking pages, stay correct
+        self.outstanding += k
         if lst:
             ptr = lst.pop()
             self._free_bytes -= k
@@ -83,6 +88,8 @@ class PinnedPool:
     @staticmethod
     def _release(pool_ref, ptr, k, ctx):
         pool = pool_ref()
+        if pool is not None:
+            pool.outstanding -= k
         if pool is not None and pool._free_bytes + k <= pool._max_free and getattr(ctx, "_h", None):
             pool._free.setdefault(k, []).append(ptr)
             pool._free_bytes += k

@@ -146,6 +146,46 @@ def test_c3_rays_against_the_float64_witness(engine):
     assert ((~h32) == (~h64)).all() or leaks_in + leaks_out > 0
 
 
+def test_other_configs_against_the_float64_witness(engine):
+    """The same witness comparison on the other kinds of input the BASELINE configs feed the cast: C1/C2 (8 x 512 in
+    synth_A1_office), C4 (BLK2GO rays with angle noise, explicit-ray kernel), the rough welded scene, and a yawed,
+    pitched sensor close to a wall.  Same bars: |t32 - t64| <= 1e-5 m, hit/miss and triangle agree (edge cases counted)."""
+    import bench
+    from lidar import DualAxisLidarIntrinsics, create_lidar
+    from lidarcast import synth
+    from oracle.c_oracle import OracleMesh
+    a1 = synth.make_scene("synth_A1_office")
+    rough = synth.make_scene("synth_rough_A6")
+    tilt = np.eye(4)
+    tilt[:3, :3] = _rot(0.9, 0.35, -0.2)
+    tilt[:3, 3] = (0.12, 2.0, 1.4)
+    np.random.seed(0)
+    cases = {
+        "C1/C2 8x512, A1": (a1, create_lidar(sensor_8x512(), pose(4.0, 3.0, 1.0)).get_rays()),
+        "C4 BLK2GO, A1": (a1, create_lidar(DualAxisLidarIntrinsics.create_blk2go_dual_axis(), pose(2.0, 3.0, 1.0, 0.4)).get_rays()),
+        "C3 sensor, rough A6": (rough, np.concatenate([create_lidar(bench.c3_sensor(), m).get_rays()
+                                                       for m in bench.c3_poses(0, 1)[[7, 50]]])),
+        "C3 sensor tilted 12 cm from a wall, A6": (None, create_lidar(bench.c3_sensor(), tilt).get_rays()),
+    }
+    a6 = synth.make_scene(bench.SCENE)
+    total = worst = 0
+    for name, (mesh, rays) in cases.items():
+        mesh = a6 if mesh is None else mesh
+        out = engine.cast_rays(rays, mesh, want=("t", "prim"))
+        t32, p32 = out["t_hit"], out["primitive_ids"]
+        t64, p64, m64 = OracleMesh(mesh.vertices, mesh.triangles).witness(rays, threads=16)
+        h32, h64 = np.isfinite(t32), np.isfinite(t64)
+        both = h32 & h64
+        dt = np.abs(t32[both].astype(np.float64) - t64[both])
+        other = both & (p32 != p64)
+        print(f"\n[witness] {name}: rays {len(rays)}, both hit {int(both.sum())}, hit/miss disagreements "
+              f"{int((h32 != h64).sum())}, other triangle {int(other.sum())}, max |dt| {dt.max():.3e} m")
+        assert dt.max() <= 1e-5 and (h32 != h64).sum() <= 2 and (m64[other] < 1e-4).all() and other.sum() <= 10
+        total += len(rays)
+        worst = max(worst, dt.max())
+    assert total > 250000
+
+
 def test_box_clause_never_acts_on_the_baseline_configs(engine):
     """The hit definition's one clause Embree does not have (t inside the padded slab interval of the triangle's own
     box) rejects nothing on C1/C2, C3 and the C5 scenes: instrumented trace kernel, counter [4] of

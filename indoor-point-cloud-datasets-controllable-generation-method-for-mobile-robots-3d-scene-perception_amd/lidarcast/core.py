@@ -366,13 +366,13 @@ class Scene:
         counts = np.zeros(P, dtype=np.uint64)
         fr.counts = counts.ctypes.data
         bufs = {}
-        self._per_pose = {}
+        per_pose = {}
         for a in want:
             if a in ("range_origin_stats", "incident_stats"):   # per-pose mean / std with numpy's arithmetic, on the device
                 col, dt = ("range_origin", np.float32) if a == "range_origin_stats" else ("incident", np.float64)
                 for kind in ("mean", "std"):
                     arr = np.zeros(P, dtype=dt)
-                    self._per_pose[f"{col}_{kind}"] = arr
+                    per_pose[f"{col}_{kind}"] = arr
                     setattr(fr, f"{col}_{kind}", arr.ctypes.data)
                 continue
             if a not in _FRAME_SPEC:
@@ -386,12 +386,14 @@ class Scene:
             else:       # a single pose's worth: page-locking a fresh buffer would cost more than the staged copy saves
                 bufs[a] = np.empty((cap,) + tail, dtype=dt)
             setattr(fr, a, bufs[a].ctypes.data)
+        bufs["__per_pose__"] = per_pose
         return fr, counts, bufs, cap
 
-    def _frames_end(self, counts, bufs, total):
+    @staticmethod
+    def _frames_end(counts, bufs, total):
+        per_pose = bufs.pop("__per_pose__")
         out = {a: b[:total] for a, b in bufs.items()}
-        out.update(self._per_pose)
-        self._per_pose = {}
+        out.update(per_pose)
         out["counts"] = counts.astype(np.int64)
         out["total"] = int(total)
         return out

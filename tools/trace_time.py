@@ -29,7 +29,8 @@ dirs = IndoorLidar(k, np.eye(4)).sensor_directions()
 poses = poses_from_waypoints(line_trajectory((1.0, Ly / 2, 1.0), (Lx - 1.0, Ly / 2, 1.0), P))
 dev = torch.device("cuda", 0)
 n = P * len(dirs)
-hits = lidarcast.DeviceHits(n, dev, want=("t", "prim", "normal3", "point3", "sem", "ins", "tile_count"))
+want = tuple(os.environ.get("LRC_TT_WANT", "t,prim,normal3,point3,sem,ins,tile_count").split(","))
+hits = lidarcast.DeviceHits(n, dev, want=want)
 d_poses, d_dirs = torch.from_numpy(poses.reshape(P, 16)).to(dev), torch.from_numpy(dirs).to(dev)
 st = torch.cuda.current_stream().cuda_stream
 grid = None

@@ -174,14 +174,23 @@ ROUGH_SCENES = {
 }
 
 
+# a large hall (~3 M triangles, ~0.3 GB of scene data: past the 256 MiB Infinity Cache) for the regime where the scene no
+# longer sits in cache; not one of the BASELINE scenes
+EXTRA_SCENES = {
+    "synth_hall": dict(size=(16.0, 12.0, 3.0), num_boxes=40, seed=11),
+}
+
+
+def _spec(name):
+    return ROUGH_SCENES.get(name) or EXTRA_SCENES.get(name) or SCENES[name]
+
+
 def make_scene(name, cell=0.02):
-    if name in ROUGH_SCENES:
-        return make_room(cell=cell, **ROUGH_SCENES[name])
-    return make_room(cell=cell, **SCENES[name])
+    return make_room(cell=cell, **_spec(name))
 
 
 def scene_size(name):
-    return (ROUGH_SCENES.get(name) or SCENES[name])["size"]
+    return _spec(name)["size"]
 
 
 def unit_cube(lo=-1.0, hi=1.0):

@@ -12,6 +12,9 @@ extern "C" {
 void orc_cast_brute(const float*, const uint32_t*, uint64_t, const float*, uint64_t, float*, uint32_t*);
 struct orc_bvh; orc_bvh* orc_bvh_build(const float*, const uint32_t*, uint64_t); void orc_bvh_free(orc_bvh*);
 void orc_cast_bvh(const orc_bvh*, const float*, uint64_t, float*, uint32_t*, int);
+void orc_cast_bvh_diag(const orc_bvh*, const float*, uint64_t, float*, uint32_t*, uint32_t*, int);
+void orc_witness_f64(const orc_bvh*, const float*, uint64_t, double*, uint32_t*, double*, int);
+void orc_witness_tri_f64(const float*, const uint32_t*, const float*, const uint32_t*, uint64_t, double*, double*);
 }
 static float rnd() { return (float)rand() / RAND_MAX; }
 int main() {
@@ -43,6 +46,19 @@ int main() {
         if (T <= 50000) {
             orc_cast_brute(v.data(), f.data(), T, rays.data(), N, t1.data(), p1.data());
             for (uint64_t i = 0; i < N; ++i) if (p1[i] != p2[i]) { printf("MISMATCH round %d ray %lu\n", round, (unsigned long)i); return 1; }
+        }
+        {   // the diagnostic cast returns the same hits; the float64 witness and its one-triangle form run clean,
+            // also on rays with non-finite components (finite-ray contract: a miss)
+            std::vector<float> t3(N); std::vector<uint32_t> p3(N), rej(N), pw(N);
+            std::vector<double> tw(N), mw(N), tt(N), mt(N);
+            orc_cast_bvh_diag(b, rays.data(), N, t3.data(), p3.data(), rej.data(), 3);
+            for (uint64_t i = 0; i < N; ++i) if (p3[i] != p2[i]) { printf("MISMATCH diag round %d ray %lu\n", round, (unsigned long)i); return 1; }
+            rays[3] = NAN; rays[6 * 7 + 1] = INFINITY;
+            orc_witness_f64(b, rays.data(), N, tw.data(), pw.data(), mw.data(), 3);
+            orc_witness_tri_f64(v.data(), f.data(), rays.data(), pw.data(), N, tt.data(), mt.data());
+            if (!std::isinf(tw[0]) || !std::isinf(tw[7])) { printf("MISMATCH non-finite ray hit, round %d\n", round); return 1; }
+            for (uint64_t i = 0; i < N; ++i)
+                if (pw[i] != 0xFFFFFFFFu && tt[i] != tw[i]) { printf("MISMATCH witness round %d ray %lu\n", round, (unsigned long)i); return 1; }
         }
         orc_bvh_free(b);
         printf("round %d T=%lu nodes=%lu depth=%u ok\n", round, (unsigned long)T, (unsigned long)h.num_nodes, h.max_depth);

@@ -129,3 +129,50 @@ def test_cloud_rebuilt_from_ids_on_adversarial_scenes(scene, num_poses, aligned)
         assert_bit_equal(t_gpu[p], np.where(keep, tb, np.inf).astype(np.float32))
         assert_bit_equal(prim_gpu[p], np.where(keep, pb, 0xFFFFFFFF).astype(np.uint32))
     sc.close()
+
+
+@pytest.mark.gpu
+@settings(max_examples=int(os.environ.get("LRC_HYPOTHESIS_EXAMPLES", 25)), deadline=None, derandomize="LRC_HYPOTHESIS_EXAMPLES" not in os.environ,
+          suppress_health_check=list(HealthCheck))
+@given(scenes(), st.integers(1, 5), st.sampled_from([0.8, 2.0, 50.0]))
+def test_frames_and_statistics_on_adversarial_scenes(scene, num_poses, max_range):
+    """lrc_scan_poses_compact on the adversarial scenes: the kept rows of every pose equal the fixed-stride records of
+    lrc_scan_poses masked on the host (ties, grazing hits, zero directions, range filter cutting through), and the
+    per-pose statistics equal np.mean / np.std of those rows bit for bit, for whatever frame sizes come out."""
+    import lidarcast
+    from helpers import pose
+    global _CTX
+    try:
+        _CTX
+    except NameError:
+        _CTX = lidarcast.Context(0)
+    v, f, rays = scene
+    dirs = np.ascontiguousarray(rays[:, 3:].astype(np.float64))
+    rng = np.random.default_rng(len(v) * 13 + num_poses)
+    poses = np.stack([pose(*rng.choice(GRID, 3), yaw=float(rng.choice([0.0, 0.5, np.pi / 2, -2.0])))
+                      for _ in range(num_poses)])
+    sc = lidarcast.Scene(_CTX, v, f)
+    rec = sc.scan_poses(poses, dirs, max_range, want=("t", "point3", "incident_deg", "sem", "ins"))
+    fr = sc.scan_poses_compact(poses, dirs, max_range, want=("point3", "incident_deg", "index", "range_origin",
+                                                             "range_origin_stats", "incident_stats"))
+    sc.close()
+    P, N = len(poses), len(dirs)
+    keep = np.isfinite(rec["t"]).reshape(P, N)
+    assert np.array_equal(fr["counts"], keep.sum(1)) and fr["total"] == keep.sum()
+    assert_bit_equal(fr["point3"], rec["point3"].reshape(P, N, 3)[keep])
+    assert_bit_equal(fr["incident_deg"], rec["incident_deg"].reshape(P, N)[keep])
+    assert np.array_equal(fr["index"], np.concatenate([np.flatnonzero(m) for m in keep]).astype(np.uint32))
+    ends = np.cumsum(fr["counts"])
+    for i in range(P):
+        r, a = fr["range_origin"][ends[i] - fr["counts"][i]:ends[i]], fr["incident_deg"][ends[i] - fr["counts"][i]:ends[i]]
+        if len(r) == 0:
+            assert fr["range_origin_mean"][i] == 0 and fr["incident_std"][i] == 0
+            continue
+        assert_bit_equal(r, np.linalg.norm(fr["point3"][ends[i] - fr["counts"][i]:ends[i]], axis=1))
+        assert_bit_equal(fr["range_origin_mean"][i:i + 1], np.array([np.mean(r)]))
+        assert_bit_equal(fr["range_origin_std"][i:i + 1], np.array([np.std(r)]))
+        with np.errstate(invalid="ignore"):
+            am, asd = np.mean(a), np.std(a)
+        if np.isfinite(am) and np.isfinite(asd):
+            assert_bit_equal(fr["incident_mean"][i:i + 1], np.array([am]))
+            assert_bit_equal(fr["incident_std"][i:i + 1], np.array([asd]))

@@ -207,9 +207,20 @@ static void select_nth(orc_bvh* b, uint32_t lo, uint32_t hi, uint32_t nth, int a
     }
 }
 
-static int32_t obuild(orc_bvh* b, uint32_t first, uint32_t count) {
-    int32_t me = (int32_t)b->num_nodes++;
-    onode* n = &b->nodes[me];
+/* Node numbering: a subtree over `count` triangles owns the index range [base, base + 2*count - 1) -- itself at `base`,
+ * its left subtree right behind it, the right one after the left one's range.  Ranges of different subtrees are
+ * disjoint, so the top of the tree can be built by several threads without any shared counter, and the result does not
+ * depend on how many threads ran. */
+typedef struct { orc_bvh* b; uint32_t first, count, base; int depth; } btask_t;
+static void obuild(orc_bvh* b, uint32_t first, uint32_t count, uint32_t base, int depth);
+static void* btask_main(void* p) {
+    btask_t* t = (btask_t*)p;
+    obuild(t->b, t->first, t->count, t->base, t->depth);
+    return NULL;
+}
+
+static void obuild(orc_bvh* b, uint32_t first, uint32_t count, uint32_t base, int depth) {
+    onode* n = &b->nodes[base];
     float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int a = 0; a < 3; ++a) { n->lo[a] = INFINITY; n->hi[a] = -INFINITY; }
     for (uint32_t i = first; i < first + count; ++i) {
@@ -222,18 +233,22 @@ static int32_t obuild(orc_bvh* b, uint32_t first, uint32_t count) {
             clo[a] = min2(clo[a], c); chi[a] = max2(chi[a], c);
         }
     }
-    if (count <= 2) { n->first = first; n->count = count; n->left = n->right = -1; return me; }
+    if (count <= 2) { n->first = first; n->count = count; n->left = n->right = -1; return; }
     int axis = 0;
     float e0 = chi[0] - clo[0], e1 = chi[1] - clo[1], e2 = chi[2] - clo[2];
     if (e1 > e0 && e1 >= e2) axis = 1; else if (e2 > e0 && e2 > e1) axis = 2;
     uint32_t half = count / 2;
     select_nth(b, first, first + count, first + half, axis);
     n->count = 0; n->first = 0;
-    int32_t l = obuild(b, first, half);
-    int32_t r = obuild(b, first + half, count - half);
-    n = &b->nodes[me];
-    n->left = l; n->right = r;
-    return me;
+    const uint32_t lbase = base + 1, rbase = base + 1 + (2 * half - 1);
+    n->left = (int32_t)lbase; n->right = (int32_t)rbase;
+    /* the first four levels fork: 16 subtrees side by side (the per-pose rebuild of the reference-faithful baseline) */
+    pthread_t th;
+    btask_t task = {b, first, half, lbase, depth + 1};
+    int forked = depth < 4 && count > 20000 && pthread_create(&th, NULL, btask_main, &task) == 0;
+    if (!forked) obuild(b, first, half, lbase, depth + 1);
+    obuild(b, first + half, count - half, rbase, depth + 1);
+    if (forked) pthread_join(th, NULL);
 }
 
 orc_bvh* orc_bvh_build(const float* verts, const uint32_t* tris, uint64_t T) {
@@ -251,7 +266,8 @@ orc_bvh* orc_bvh_build(const float* verts, const uint32_t* tris, uint64_t T) {
         tri_box(b, (uint32_t)k, lo, hi);
         for (int a = 0; a < 3; ++a) b->cent[3 * k + a] = 0.5f * lo[a] + 0.5f * hi[a];
     }
-    obuild(b, 0, (uint32_t)T);
+    obuild(b, 0, (uint32_t)T, 0, 0);
+    b->num_nodes = (uint32_t)(2 * T - 1);
     return b;
 }
 

@@ -619,6 +619,10 @@ def test_examples_run(tmp_path):
                         str(tmp_path / "out"), "--waypoints", "4"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-1500:]
     assert "combined_pointcloud_with_label.ply" in r.stdout and "planned" in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(REPO, "examples", "scan_trajectory.py")], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "scan_frames   : 16 frames" in r.stdout and "run_simulation: 16 frames" in r.stdout
 
 
 def test_many_short_poses(ctx):

@@ -599,3 +599,42 @@ def test_device_frame_statistics_carry_numpys_bits(engine):
         assert q.num_points == len(f.points) > 1000
         assert q.range_mean == np.mean(r) and q.range_std == np.std(r) and type(q.range_mean) is np.float32
         assert q.incident_angle_mean == np.mean(f.incident_angles) and q.incident_angle_std == np.std(f.incident_angles)
+
+
+def test_frames_entry_point_edge_cases(engine):
+    """lrc_scan_poses_compact off the beaten path: an empty mesh, one pose, a ray count that is not a multiple of 64
+    (no fused keep counts, no chunking), and 70 poses x 16 384 rays (the chunked pipeline with uneven chunks 17/18/17/18)
+    against the fixed-stride records; statistics against numpy every time."""
+    from lidar import Indoor8LineLidarIntrinsics
+    from lidarcast import synth
+    from lidarcast.synth import TriangleMesh
+    room = synth.make_room(size=(4, 3, 2.5), num_boxes=3, seed=9, cell=0.05)
+    empty = TriangleMesh(np.zeros((0, 3)), np.zeros((0, 3), np.int32))
+    big = Indoor8LineLidarIntrinsics(vertical_res=16, horizontal_res=1024, max_range=2.4,
+                                     vertical_degrees=list(np.linspace(20, -25, 16)))
+    odd = Indoor8LineLidarIntrinsics(vertical_res=5, horizontal_res=20, max_range=30.0,
+                                     vertical_degrees=[10.0, 5.0, 0.0, -5.0, -10.0])
+    cases = [(empty, sensor_small(lines=4, width=64), 3), (room, sensor_small(lines=4, width=64), 1), (room, odd, 6),
+             (room, big, 70)]
+    for mesh, k, n_poses in cases:
+        poses = np.stack([pose(0.7 + 2.6 * i / max(n_poses - 1, 1), 1.5, 1.1, 0.05 * i) for i in range(n_poses)])
+        rec, n = engine.scan_poses(k, poses, mesh, want=("t", "point3", "incident_deg"))
+        fr = engine.scan_frames(k, poses, mesh, want=("point3", "incident_deg", "range_origin", "range_origin_stats",
+                                                      "incident_stats"))
+        keep = np.isfinite(rec["t"])
+        assert np.array_equal(fr["counts"], keep.sum(1)) and fr["total"] == keep.sum()
+        assert_bit_equal(fr["point3"], rec["point3"][keep])
+        assert_bit_equal(fr["incident_deg"], rec["incident_deg"][keep])
+        ends = np.cumsum(fr["counts"])
+        for i in range(n_poses):
+            r = fr["range_origin"][ends[i] - fr["counts"][i]:ends[i]]
+            a = fr["incident_deg"][ends[i] - fr["counts"][i]:ends[i]]
+            if len(r) == 0:
+                assert fr["range_origin_mean"][i] == 0 and fr["range_origin_std"][i] == 0
+                continue
+            assert fr["range_origin_mean"][i] == np.mean(r) and fr["range_origin_std"][i] == np.std(r)
+            assert fr["incident_mean"][i] == np.mean(a) and fr["incident_std"][i] == np.std(a)
+        if mesh is empty:
+            assert fr["total"] == 0
+        if n_poses == 70:
+            assert fr["total"] > 3e5 and 0.1 < keep.mean() < 0.9        # the range filter cuts through: ragged frames

@@ -35,22 +35,22 @@ def mesh_arrays(mesh):
 
 def _fingerprint(v, f, full=False):
     """Cache key of a mesh's arrays.  ``full=False`` (the default on the per-waypoint call path, where the reference
-    calls the engine once per pose with the same mesh object) hashes both ends of each array plus 4096 rows spread
-    evenly over the whole of it: it costs microseconds and notices a replaced or re-generated mesh, but an in-place
-    edit of a few rows in the middle of a large array can escape it -- after editing a mesh in place call
-    ``engine.clear_cache()`` (or construct the engine with ``cache_check="full"``, which hashes every byte:
+    calls the engine once per pose with the same mesh object) hashes 4 KB from both ends of each array plus 256 rows
+    spread evenly over the whole of it: ~20 microseconds (a 65 k-ray call takes 230), enough to notice a replaced or
+    re-generated mesh; an in-place edit of a few rows of a large array can escape it -- after editing a mesh in place
+    call ``engine.clear_cache()`` (or construct the engine with ``cache_check="full"``, which hashes every byte:
     milliseconds per call on a million-triangle mesh)."""
     h = hashlib.blake2b(digest_size=16)
     for a in (v, f):
         a = np.ascontiguousarray(a)
         b = a.view(np.uint8).reshape(-1)
-        if full or b.size <= (1 << 18):
+        if full or b.size <= (1 << 15):
             h.update(b.tobytes())
         else:
-            h.update(b[:1 << 16].tobytes())
-            h.update(b[-(1 << 16):].tobytes())
+            h.update(b[:4096].tobytes())
+            h.update(b[-4096:].tobytes())
             rows = a.reshape(len(a), -1)
-            h.update(np.ascontiguousarray(rows[::max(1, len(rows) // 4096)]).tobytes())
+            h.update(np.ascontiguousarray(rows[::max(1, len(rows) // 256)]).tobytes())
     return (v.shape, f.shape, str(v.dtype), str(f.dtype), h.hexdigest())
 
 

@@ -1,5 +1,11 @@
-import sys, os, time
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""tools/compact_time.py -- wall time of the frame-producing call (lrc_scan_poses_compact) on the C3 workload for several
+sets of requested columns, with and without the device-side per-pose statistics."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, numpy as np, lidarcast
 from lidarcast import synth
 from lidar import IndoorLidar

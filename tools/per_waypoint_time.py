@@ -1,5 +1,11 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""tools/per_waypoint_time.py -- where one per-waypoint drop-in call (RaycastEngineGPU.lidar_intersect_mesh, 65 536 rays)
+spends its time: scene cache lookup, direction table, the library call."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, numpy as np
 from lidarcast import synth
 from lidar import create_lidar

@@ -277,6 +277,19 @@ int lrc_scan_angles_compact(lrc_scene* scene, const double* poses16, uint64_t nu
                             const uint8_t* keep, uint64_t rays_per_pose, double max_range, const lrc_frames* out,
                             uint64_t capacity, uint64_t* out_total);
 
+/* ---- explicit rays of several poses straight to frames --------------------------------------------------------
+ * The frame-producing form of lrc_cast_segments for sensors whose rays come from the host generator (the dual-axis
+ * sensor's bit-exact default path): every pose contributes rays_per_pose rays at a fixed stride,
+ *   rays6    : (num_poses * rays_per_pose, 6) float32, pose-major
+ *   keep     : nullable (num_poses * rays_per_pose) bytes, 0 = ray dropped by the sensor (lidar/indoor_lidar.py:292-294):
+ *              never cast, reported as a miss -- the frames equal those of casting only the kept rays
+ *   centers3 : (num_poses, 3) float64 range-filter centres (pose[:3,3])
+ * and the result is compacted in HBM exactly like lrc_scan_poses_compact's (same lrc_frames, same ordering, per-pose
+ * statistics included).  `index` is then the ray's index among ALL rays_per_pose rays of its pose. */
+int lrc_scan_rays_compact(lrc_scene* scene, const float* rays6, const uint8_t* keep, const double* centers3,
+                          uint64_t num_poses, uint64_t rays_per_pose, double max_range, const lrc_frames* out,
+                          uint64_t capacity, uint64_t* out_total);
+
 /* ---- diagnostics ---------------------------------------------------------------------------------------
  * Per-ray traversal counters of a pose-batched scan from an instrumented build of the trace kernel, host arrays.
  * stats: (num_poses * rays_per_pose, LRC_STATS_WORDS) uint32: [0] inner-node steps, [1] triangle tests, [2] node steps

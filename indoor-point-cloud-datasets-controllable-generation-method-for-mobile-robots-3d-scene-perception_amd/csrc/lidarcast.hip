@@ -363,7 +363,12 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
         const float* r = p.rays6 + gid * 6;
         o.x = r[0]; o.y = r[1]; o.z = r[2];
         d.x = r[3]; d.y = r[4]; d.z = r[5];
-        if (p.seg_offsets) {
+        if (p.keep_mask) live = p.keep_mask[gid] != 0;          // rays the sensor dropped: never cast
+        if (!p.seg_offsets && p.seg_centers3) {
+            // explicit rays of several poses at a FIXED stride (rays_per_pose each, dropped ones masked): pose = gid / N
+            const double* c = p.seg_centers3 + (size_t)(gid / p.rays_per_pose) * 3;
+            cx = c[0]; cy = c[1]; cz = c[2];
+        } else if (p.seg_offsets) {
             // rays of several poses back to back: find this ray's pose (largest s with off[s] <= gid)
             uint32_t lo = 0, hi = p.num_segments;
             while (hi - lo > 1) {
@@ -1723,6 +1728,8 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
         TraceParams q = p;
         q.poses16 = p.poses16 + p0 * 16;
         if (q.angles2) q.angles2 = p.angles2 + r0 * 2;
+        if (q.rays6) q.rays6 = p.rays6 + r0 * 6;
+        if (q.seg_centers3) q.seg_centers3 = p.seg_centers3 + p0 * 3;
         if (q.keep_mask) q.keep_mask = p.keep_mask + r0;
         q.total = np_ * N;
         q.range_noise = nullptr;
@@ -1940,6 +1947,39 @@ int lrc_scan_angles_compact(lrc_scene* s, const double* poses16, uint64_t P, con
     p.has_center = 1;
     p.max_range = max_range;
     return frames_finish(s, p, 2, st, P, N, out, capacity, out_total);
+}
+
+int lrc_scan_rays_compact(lrc_scene* s, const float* rays6, const uint8_t* keep, const double* centers3, uint64_t P,
+                          uint64_t N, double max_range, const lrc_frames* out, uint64_t capacity, uint64_t* out_total) {
+    if (out_total) *out_total = 0;
+    if (!s || !out) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_rays_compact: NULL scene or output");
+    const uint64_t n = P * N;
+    if (!n) return LRC_OK;
+    if (!rays6 || !centers3 || !out->counts)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_scan_rays_compact: rays6, centers3 or counts is NULL");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    DevBuf dr, dc, dk;
+    int rc;
+    if ((rc = dr.get(s->ctx, kPoolRays, n * 24)) || (rc = dc.get(s->ctx, kPoolCen, P * 24))) return rc;
+    LRC_HIP(hipMemcpyAsync(dr.p, rays6, n * 24, hipMemcpyHostToDevice, nullptr));
+    LRC_HIP(hipMemcpyAsync(dc.p, centers3, P * 24, hipMemcpyHostToDevice, nullptr));
+    if (keep) {
+        if ((rc = dk.get(s->ctx, kPoolKeep, n))) return rc;
+        LRC_HIP(hipMemcpyAsync(dk.p, keep, n, hipMemcpyHostToDevice, nullptr));
+    }
+    FrameStage st;
+    if ((rc = st.alloc(s->ctx, *out, P, n))) return rc;
+    NoiseStage ns;
+    if ((rc = ns.begin(s, n))) return rc;
+    TraceParams p{};
+    p.rays6 = (const float*)dr.p;
+    p.seg_centers3 = (const double*)dc.p;
+    p.keep_mask = keep ? (const uint8_t*)dk.p : nullptr;
+    p.rays_per_pose = N;
+    p.total = n;
+    p.has_center = 1;
+    p.max_range = max_range;
+    return frames_finish(s, p, 0, st, P, N, out, capacity, out_total);
 }
 
 int lrc_debug_scan_stats(lrc_scene* s, const double* poses16, uint64_t P, const double* dirs3, uint64_t N,

@@ -145,16 +145,23 @@ class DualAxisLidar:
             keep = rnd.random(n) > k.dropout_probability
         return phi, theta, keep
 
-    def get_multi_line_rays(self, num_points: int = None) -> np.ndarray:
+    def all_rays_and_mask(self, num_points: int = None, out: np.ndarray = None):
+        """Every ray of the scan BEFORE the dropout, (N,6) float32 (written into ``out`` when given, e.g. a page-locked
+        buffer), and the dropout keep mask (N,) bool or None.  ``rays[keep]`` is ``get_multi_line_rays()``; consumes the
+        RNG exactly as it does.  The batched engine path casts all rays with the mask instead of a ragged subset."""
         phi, theta, keep = self.scan_angles(num_points)
         ct = np.cos(theta)
         d = np.stack([ct * np.cos(phi), ct * np.sin(phi), np.sin(theta)], axis=-1)
         R = self.pose[:3, :3]
         # the reference rotates ray by ray (R @ d); row form of the same product
         world = (d[:, 0:1] * R[:, 0][None, :] + d[:, 1:2] * R[:, 1][None, :]) + d[:, 2:3] * R[:, 2][None, :]
-        rays = np.empty((len(d), 6), dtype=np.float32)
+        rays = np.empty((len(d), 6), dtype=np.float32) if out is None else out
         rays[:, :3] = self.pose[:3, 3].astype(np.float32)
         rays[:, 3:] = world.astype(np.float32)
+        return rays, keep
+
+    def get_multi_line_rays(self, num_points: int = None) -> np.ndarray:
+        rays, keep = self.all_rays_and_mask(num_points)
         if keep is not None:
             rays = rays[keep]
         return rays

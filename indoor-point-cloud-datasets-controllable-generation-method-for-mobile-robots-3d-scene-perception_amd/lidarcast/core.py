@@ -444,6 +444,24 @@ class Scene:
                                                 C.byref(fr), cap, C.byref(total)), "lrc_scan_angles_compact")
         return self._frames_end(counts, bufs, total.value)
 
+    def scan_rays_compact(self, rays, keep, centers, max_range, want=("point3", "sem", "ins"), capacity=None):
+        """Host-generated rays of several poses at a fixed stride straight to frames (lrc_scan_rays_compact).
+        rays: (P, N, 6) float32; keep: (P, N) bool / uint8 or None; centers: (P, 3) float64."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        if rays.ndim != 3 or rays.shape[2] != 6:
+            raise ValueError("rays must be (P, N, 6)")
+        P, N = rays.shape[0], rays.shape[1]
+        cen = np.ascontiguousarray(centers, dtype=np.float64).reshape(P, 3)
+        k8 = None
+        if keep is not None:
+            k8 = np.ascontiguousarray(keep).reshape(P, N).view(np.uint8) if np.asarray(keep).dtype == np.bool_ \
+                else np.ascontiguousarray(keep, dtype=np.uint8).reshape(P, N)
+        fr, counts, bufs, cap = self._frames_begin(P, P * N, want, capacity)
+        total = C.c_uint64(0)
+        check(self._lib.lrc_scan_rays_compact(self._h, _ptr(rays), _ptr(k8), _ptr(cen), P, N, float(max_range),
+                                              C.byref(fr), cap, C.byref(total)), "lrc_scan_rays_compact")
+        return self._frames_end(counts, bufs, total.value)
+
     def scan_stats(self, poses, dirs, max_range):
         """(P*N, 5) uint32 traversal counters per ray from the instrumented trace kernel (lrc_debug_scan_stats):
         node steps, triangle tests, wave-uniform node steps, dead node steps, pad-clause rejections."""

@@ -244,6 +244,29 @@ class RaycastEngineHIP(RaycastEngineBase):
                                                        intrinsics.max_range, want=want,
                                                        grid=self._grid_of(intrinsics, len(poses)))
 
+    def scan_frames_lidars(self, lidars, mesh, want=("point3", "sem", "ins")):
+        """The bit-exact default path of the dual-axis sensor, straight to frames: every pose's rays come from the host
+        generator (``all_rays_and_mask``: the reference's arithmetic and RNG draws, written into a page-locked buffer),
+        ALL of them are uploaded at a fixed stride with the dropout mask, dropped rays are never cast, compaction and
+        the per-pose statistics happen in HBM (lrc_scan_rays_compact).  Same frames as ``scan_lidars`` + host masking;
+        same return value as ``scan_frames``."""
+        if len(lidars) == 0:
+            raise ValueError("no lidars given")
+        k0 = lidars[0].intrinsics
+        n = k0.num_vertical_lines * (int(k0.point_rate * k0.scan_duration) // k0.num_vertical_lines)
+        P = len(lidars)
+        rays = self.ctx.pinned.take(P * n * 24)[:P * n * 24].view(np.float32).reshape(P, n, 6)
+        keep = self.ctx.pinned.take(P * n)[:P * n].reshape(P, n)
+        keep[:] = 1
+        for i, l in enumerate(lidars):
+            r, k = l.all_rays_and_mask(out=rays[i])
+            if len(r) != n:
+                raise ValueError("dual-axis poses must share one ray count")
+            if k is not None:
+                keep[i] = k
+        centers = np.stack([np.asarray(l.pose, dtype=np.float64)[:3, 3] for l in lidars])
+        return self.scene_for(mesh).scan_rays_compact(rays, keep, centers, k0.max_range, want=want)
+
     def scan_frames_dual_axis(self, lidars, mesh, want=("point3", "sem", "ins")):
         """Opt-in fast path of the dual-axis sensor: the noisy scan angles and the dropout mask are drawn on the host
         from the numpy stream, pose after pose, exactly as ``get_rays()`` would draw them (the seeded stream is the

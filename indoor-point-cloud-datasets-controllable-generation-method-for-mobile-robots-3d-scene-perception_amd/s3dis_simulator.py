@@ -241,8 +241,14 @@ class S3DISSimulator:
             # opt-in: dual-axis rays generated in the kernel from the host-drawn scan angles
             lidars = [create_lidar(self.lidar_config, wp.to_pose_matrix()) for wp in waypoints]
             fr = engine.scan_frames_dual_axis(lidars, mesh, want=want)
+        elif len(waypoints) > 0 and isinstance(self.lidar_config, DualAxisLidarIntrinsics) and \
+                hasattr(engine, "scan_frames_lidars"):
+            # host-generated rays (dual-axis sensor, the bit-exact default): all rays of all poses at a fixed stride with
+            # the dropout mask, one launch, compaction and statistics in HBM
+            lidars = [create_lidar(self.lidar_config, wp.to_pose_matrix()) for wp in waypoints]
+            fr = engine.scan_frames_lidars(lidars, mesh, want=want)
         elif len(waypoints) > 0:
-            # host-generated rays (dual-axis sensor, the bit-exact default): all poses in one launch, ragged segments
+            # any other sensor object with get_rays(): all poses in one launch, ragged segments, masked on the host
             lidars = [create_lidar(self.lidar_config, wp.to_pose_matrix()) for wp in waypoints]
             seg, off = engine.scan_lidars(lidars, mesh, want=("t", "point3", "incident_deg", "sem", "ins"))
         if fr is not None:

@@ -638,3 +638,34 @@ def test_frames_entry_point_edge_cases(engine):
             assert fr["total"] == 0
         if n_poses == 70:
             assert fr["total"] > 3e5 and 0.1 < keep.mean() < 0.9        # the range filter cuts through: ragged frames
+
+
+def test_dual_axis_default_path_to_frames(engine):
+    """lrc_scan_rays_compact (all host-generated rays at a fixed stride + dropout mask, compaction in HBM) against
+    lrc_cast_segments on the ragged kept rays + host masking: the same frames bit for bit on the same seeded stream,
+    the same number of RNG draws, statistics equal to numpy's."""
+    from lidar import DualAxisLidarIntrinsics, create_lidar
+    from lidarcast import synth
+    mesh = synth.make_room(size=(6, 5, 3), num_boxes=8, seed=2, cell=0.04)
+    kd = DualAxisLidarIntrinsics.create_blk2go_dual_axis()
+    poses = [pose(1.0 + 0.5 * i, 2.5, 1.0, 0.25 * i) for i in range(5)]
+    np.random.seed(11)
+    rec, off = engine.scan_lidars([create_lidar(kd, m) for m in poses], mesh, want=("t", "point3", "sem", "ins", "incident_deg"))
+    end_a = np.random.random()
+    np.random.seed(11)
+    fr = engine.scan_frames_lidars([create_lidar(kd, m) for m in poses], mesh,
+                                   want=("point3", "sem", "ins", "incident_deg", "range_origin_stats", "incident_stats"))
+    assert np.random.random() == end_a
+    keep = np.isfinite(rec["t"])
+    assert fr["total"] == keep.sum() > 5 * 60000
+    assert np.array_equal(fr["counts"], [int(keep[off[i]:off[i + 1]].sum()) for i in range(5)])
+    assert_bit_equal(fr["point3"], rec["point3"][keep])
+    assert_bit_equal(fr["incident_deg"], rec["incident_deg"][keep])
+    assert np.array_equal(fr["sem"], rec["sem"][keep]) and np.array_equal(fr["ins"], rec["ins"][keep])
+    ends = np.cumsum(fr["counts"])
+    for i in range(5):
+        pts = fr["point3"][ends[i] - fr["counts"][i]:ends[i]]
+        r = np.linalg.norm(pts, axis=1)
+        assert fr["range_origin_mean"][i] == np.mean(r) and fr["range_origin_std"][i] == np.std(r)
+        a = fr["incident_deg"][ends[i] - fr["counts"][i]:ends[i]]
+        assert fr["incident_mean"][i] == np.mean(a) and fr["incident_std"][i] == np.std(a)

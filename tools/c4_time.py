@@ -3,6 +3,8 @@
 synth_A1_office, 64 000 rays per pose before the 2 % dropout) through the plugin surface, three ways:
   host generator      RaycastEngineGPU.scan_lidars: rays from the vectorised host generator (bit-exact to the
                       reference's), one lrc_cast_segments launch, fixed-stride records back over PCIe   [round 1 path]
+  host generator to frames   RaycastEngineGPU.scan_frames_lidars: the same rays, all of them at a fixed stride with the
+                      dropout mask in page-locked memory, compaction in HBM (lrc_scan_rays_compact)   [the default now]
   device generator    RaycastEngineGPU.scan_frames_dual_axis: scan angles drawn on the host (the seeded stream), rays
                       formed in the kernel, compaction in HBM, kept rows into page-locked memory
   and the stages of the second: host RNG + angle formulae alone, the library call alone (angles already in page-locked
@@ -41,6 +43,7 @@ def lidars():
 
 
 for name, fn in (("host_generator", lambda: eng.scan_lidars(lidars(), mesh, want=("t", "point3", "sem", "ins"))),
+                 ("host_generator_to_frames", lambda: eng.scan_frames_lidars(lidars(), mesh, want=("point3", "sem", "ins"))),
                  ("device_generator", lambda: eng.scan_frames_dual_axis(lidars(), mesh, want=("point3", "sem", "ins")))):
     ts = []
     for _ in range(3):

@@ -373,9 +373,10 @@ def _simulate(distributed):
     return h, counts.tolist(), float(scene.frames[0].scan_quality.range_mean)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_rank_aware_run_simulation(world):
-    """S3DISSimulator.run_simulation inside a gloo job of 2 and 3 ranks (ragged pose blocks 4+3 / 3+2+2): every rank
+    """S3DISSimulator.run_simulation inside a gloo job of 2, 3, 4 and 8 ranks (ragged pose blocks 4+3 / 3+2+2 / 2+2+2+1 /
+    seven ranks with one pose and one with none): every rank
     gets the frames of ALL poses, hash-identical to the single-process assembly, and builds the same statistics."""
     from helpers import sensor_small
     from lidar import create_lidar

@@ -255,6 +255,18 @@ int lrc_scan_grid_compact(lrc_scene* scene, const double* poses16, uint64_t num_
                           const lrc_grid* grid, double max_range, const lrc_frames* out, uint64_t capacity,
                           uint64_t* out_total);
 
+/* ---- a sensor's direction table resident in HBM -------------------------------------------------------------
+ * A caller that scans pose after pose with the same sensor (the reference's per-waypoint loop,
+ * s3dis_simulator.py:254-264) would upload the same (N,3) float64 table with every call; a table handle uploads it
+ * once.  lrc_scan_table_compact is lrc_scan_poses_compact (grid == NULL) or lrc_scan_grid_compact (grid != NULL) on
+ * that resident table. */
+typedef struct lrc_table lrc_table;
+int lrc_table_create(lrc_ctx* ctx, const double* dirs3, uint64_t rays_per_pose, lrc_table** out_table);
+int lrc_table_destroy(lrc_table* table);
+int lrc_scan_table_compact(lrc_scene* scene, const double* poses16, uint64_t num_poses, const lrc_table* table,
+                           const lrc_grid* grid /* nullable */, double max_range, const lrc_frames* out,
+                           uint64_t capacity, uint64_t* out_total);
+
 /* Page-locked host memory for the frame buffers above (hipHostMalloc / hipHostFree).  The caller owns it. */
 int lrc_host_alloc(lrc_ctx* ctx, uint64_t bytes, void** out_ptr);
 int lrc_host_free(lrc_ctx* ctx, void* ptr);

@@ -94,6 +94,12 @@ struct lrc_ctx {
     uint64_t h_counts_cap = 0;          // need one): counts (P u64) | 4 x P doubles of per-pose statistics
 };
 
+struct lrc_table {            // a sensor's direction table resident in HBM (lrc_table_create)
+    lrc_ctx* ctx = nullptr;
+    double* d_dirs3 = nullptr;
+    uint64_t n = 0;
+};
+
 struct lrc_scene {
     lrc_ctx* ctx = nullptr;
     float4* d_nodes = nullptr;
@@ -1848,7 +1854,48 @@ int lrc_host_free(lrc_ctx* ctx, void* ptr) {
 
 static int scan_compact_impl(lrc_scene* s, const double* poses16, uint64_t P, const double* dirs3, uint64_t N,
                              const lrc_grid* grid, double max_range, const lrc_frames* out, uint64_t capacity,
-                             uint64_t* out_total);
+                             uint64_t* out_total, const double* d_dirs3 = nullptr);
+
+int lrc_table_create(lrc_ctx* ctx, const double* dirs3, uint64_t N, lrc_table** out_table) {
+    if (!out_table) return fail(LRC_ERR_INVALID_ARG, "lrc_table_create: out_table is NULL");
+    *out_table = nullptr;
+    if (!ctx || !dirs3 || !N) return fail(LRC_ERR_INVALID_ARG, "lrc_table_create: NULL context / table or empty table");
+    LRC_HIP(hipSetDevice(ctx->device));
+    lrc_table* t = new (std::nothrow) lrc_table();
+    if (!t) return fail(LRC_ERR_OOM, "lrc_table_create: out of host memory");
+    t->ctx = ctx;
+    t->n = N;
+    hipError_t e = hipMalloc((void**)&t->d_dirs3, N * 24);
+    if (e == hipSuccess) e = hipMemcpy(t->d_dirs3, dirs3, N * 24, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (t->d_dirs3) (void)hipFree(t->d_dirs3);
+        delete t;
+        return fail(e == hipErrorOutOfMemory ? LRC_ERR_OOM : LRC_ERR_HIP, std::string("lrc_table_create: ") + hipGetErrorString(e));
+    }
+    *out_table = t;
+    return LRC_OK;
+}
+
+int lrc_table_destroy(lrc_table* t) {
+    if (!t) return LRC_OK;
+    if (t->ctx) (void)hipSetDevice(t->ctx->device);
+    if (t->d_dirs3) (void)hipFree(t->d_dirs3);
+    delete t;
+    return LRC_OK;
+}
+
+int lrc_scan_table_compact(lrc_scene* s, const double* poses16, uint64_t P, const lrc_table* table, const lrc_grid* grid,
+                           double max_range, const lrc_frames* out, uint64_t capacity, uint64_t* out_total) {
+    if (out_total) *out_total = 0;
+    if (!table) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_table_compact: table is NULL");
+    if (s && table->ctx != s->ctx) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_table_compact: table and scene belong to different contexts");
+    if (grid) {
+        int rc = check_grid("lrc_scan_table_compact", grid, table->n);
+        if (rc) return rc;
+    }
+    return scan_compact_impl(s, poses16, P, nullptr, table->n, grid, max_range, out, capacity, out_total, table->d_dirs3);
+}
 
 int lrc_scan_poses_compact(lrc_scene* s, const double* poses16, uint64_t P, const double* dirs3, uint64_t N,
                            double max_range, const lrc_frames* out, uint64_t capacity, uint64_t* out_total) {
@@ -1867,19 +1914,24 @@ int lrc_scan_grid_compact(lrc_scene* s, const double* poses16, uint64_t P, const
 
 static int scan_compact_impl(lrc_scene* s, const double* poses16, uint64_t P, const double* dirs3, uint64_t N,
                              const lrc_grid* grid, double max_range, const lrc_frames* out, uint64_t capacity,
-                             uint64_t* out_total) {
+                             uint64_t* out_total, const double* d_dirs3) {
     if (out_total) *out_total = 0;
     if (!s || !out) return fail(LRC_ERR_INVALID_ARG, "lrc_scan_poses_compact: NULL scene or output");
     const uint64_t n = P * N;
     if (!n) return LRC_OK;
-    if (!poses16 || !dirs3 || !out->counts)
+    if (!poses16 || (!dirs3 && !d_dirs3) || !out->counts)
         return fail(LRC_ERR_INVALID_ARG, "lrc_scan_poses_compact: poses16, dirs3 or counts is NULL");
     LRC_HIP(hipSetDevice(s->ctx->device));
     DevBuf dp, dd;
     int rc;
-    if ((rc = dp.get(s->ctx, kPoolPoses, P * 128)) || (rc = dd.get(s->ctx, kPoolDirs, N * 24))) return rc;
+    if ((rc = dp.get(s->ctx, kPoolPoses, P * 128))) return rc;
     LRC_HIP(hipMemcpyAsync(dp.p, poses16, P * 128, hipMemcpyHostToDevice, nullptr));
-    LRC_HIP(hipMemcpyAsync(dd.p, dirs3, N * 24, hipMemcpyHostToDevice, nullptr));
+    if (d_dirs3) {
+        dd.p = (void*)d_dirs3; dd.pooled = true;            // resident table (lrc_table): nothing to upload
+    } else {
+        if ((rc = dd.get(s->ctx, kPoolDirs, N * 24))) return rc;
+        LRC_HIP(hipMemcpyAsync(dd.p, dirs3, N * 24, hipMemcpyHostToDevice, nullptr));
+    }
     FrameStage st;
     if ((rc = st.alloc(s->ctx, *out, P, n))) return rc;
     NoiseStage ns;

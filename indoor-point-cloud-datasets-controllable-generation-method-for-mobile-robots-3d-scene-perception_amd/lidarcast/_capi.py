@@ -29,6 +29,7 @@ SYMBOLS = (
     "lrc_scan_poses", "lrc_scan_poses_dev", "lrc_scan_poses_compact", "lrc_host_alloc", "lrc_host_free",
     "lrc_scan_angles_dev", "lrc_scan_angles_compact", "lrc_debug_scan_stats",
     "lrc_scan_grid_dev", "lrc_scan_grid_compact", "lrc_scan_rays_compact",
+    "lrc_table_create", "lrc_table_destroy", "lrc_scan_table_compact",
     "lrc_compact", "lrc_compact_dev", "lrc_cloud_from_ranges_dev", "lrc_cloud_from_prims_dev",
     "lrc_nn_create", "lrc_nn_destroy", "lrc_nn_query", "lrc_nn_query_dev",
     "lrc_min_distances", "lrc_rbf_kernel_sum",
@@ -123,6 +124,9 @@ def load():
         "lrc_scan_angles_compact": [vp, vp, u64, vp, vp, u64, dbl, C.POINTER(LrcFrames), u64, C.POINTER(u64)],
         "lrc_debug_scan_stats": [vp, vp, u64, vp, u64, dbl, vp],
         "lrc_scan_rays_compact": [vp, vp, vp, vp, u64, u64, dbl, C.POINTER(LrcFrames), u64, C.POINTER(u64)],
+        "lrc_table_create": [vp, vp, u64, C.POINTER(vp)],
+        "lrc_table_destroy": [vp],
+        "lrc_scan_table_compact": [vp, vp, u64, vp, C.POINTER(LrcGrid), dbl, C.POINTER(LrcFrames), u64, C.POINTER(u64)],
         "lrc_scan_grid_dev": [vp, vp, u64, vp, C.POINTER(LrcGrid), dbl, C.POINTER(LrcHits), vp],
         "lrc_scan_grid_compact": [vp, vp, u64, vp, C.POINTER(LrcGrid), dbl, C.POINTER(LrcFrames), u64, C.POINTER(u64)],
         "lrc_occ_create": [vp, vp, u64, C.POINTER(vp)],

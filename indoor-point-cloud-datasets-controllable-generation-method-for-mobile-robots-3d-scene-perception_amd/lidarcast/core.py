@@ -221,6 +221,32 @@ class DeviceHits:
                    if a not in ("tile_count", "t_label"))
 
 
+class DirectionTable:
+    """A sensor's (N,3) float64 direction table resident in HBM (lrc_table_create): per-pose callers upload it once."""
+
+    def __init__(self, ctx, dirs):
+        self._lib = _capi.load()
+        self.ctx = ctx
+        d = np.ascontiguousarray(dirs, dtype=np.float64)
+        if d.ndim != 2 or d.shape[1] != 3 or len(d) == 0:
+            raise ValueError("dirs must be a non-empty (N, 3) array")
+        h = C.c_void_p()
+        check(self._lib.lrc_table_create(ctx._h, _ptr(d), len(d), C.byref(h)), "lrc_table_create")
+        self._h, self.n = h, len(d)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if getattr(self.ctx, "_h", None):
+                self._lib.lrc_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Scene:
     """A triangle mesh and its BVH, resident in HBM.  Built once, cast many times."""
 
@@ -410,6 +436,15 @@ class Scene:
         [counts[:p].sum(), counts[:p+1].sum()).  ``grid`` = (lines, width, az0, az_step) of a table that is a
         (scan line x azimuth) grid selects the packet kernel (lrc_scan_grid_compact): same bytes, faster."""
         poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 16)
+        if isinstance(dirs, DirectionTable):          # resident table: nothing to upload
+            P, N = poses.shape[0], dirs.n
+            fr, counts, bufs, cap = self._frames_begin(P, P * N, want, capacity)
+            total = C.c_uint64(0)
+            g = None if grid is None else self._grid_struct(grid)
+            check(self._lib.lrc_scan_table_compact(self._h, _ptr(poses), P, dirs._h, None if g is None else C.byref(g),
+                                                   float(max_range), C.byref(fr), cap, C.byref(total)),
+                  "lrc_scan_table_compact")
+            return self._frames_end(counts, bufs, total.value)
         dirs = np.ascontiguousarray(dirs, dtype=np.float64)
         if dirs.ndim != 2 or dirs.shape[1] != 3:
             raise ValueError("dirs must be (N, 3)")

@@ -65,6 +65,7 @@ class RaycastEngineHIP(RaycastEngineBase):
         self._scenes = {}                   # id(mesh) -> (weakref or None, fingerprint, Scene)
         self._dir_tables = {}
         self._grids = {}
+        self._dev_tables = {}
         # The packet kernel (lrc_scan_grid_*, csrc/lrc_sector.h) returns the same bytes as the per-ray kernel and is
         # kept as a measured alternative: on the benchmark scenes it is 3-10x SLOWER, so it is
         # off unless asked for.
@@ -99,6 +100,9 @@ class RaycastEngineHIP(RaycastEngineBase):
         for ent in self._scenes.values():
             ent[2].close()
         self._scenes.clear()
+        for ent in self._dev_tables.values():
+            ent[1].close()
+        self._dev_tables.clear()
 
     # ---- reference interface ------------------------------------------------------------------------
     @staticmethod
@@ -189,6 +193,18 @@ class RaycastEngineHIP(RaycastEngineBase):
             np.abs(ch ** 2 + t[:, 0, 2] ** 2 - 1).max() < 1e-12
         return (H, W, float(az[0]), float(step)) if ok else None
 
+    def _resident_table(self, intrinsics):
+        """The sensor's direction table as a handle resident in HBM, created on first use, kept with the host table."""
+        from lidarcast import DirectionTable
+        tab = self._direction_table(intrinsics)
+        ent = self._dev_tables.get(id(tab))
+        if ent is None or ent[0] is not tab:
+            ent = (tab, DirectionTable(self.ctx, tab))
+            if len(self._dev_tables) >= 8:
+                self._dev_tables.pop(next(iter(self._dev_tables)))[1].close()
+            self._dev_tables[id(tab)] = ent
+        return ent[1]
+
     def lidar_intersect_mesh(self, lidar, mesh):
         from lidar import IndoorLidar
         scene = self.scene_for(mesh)
@@ -197,7 +213,7 @@ class RaycastEngineHIP(RaycastEngineBase):
             # (bit-identical to lidar.get_rays(), rotated poses included) instead of on the host
             # ... and compacted in HBM: only the kept points and angles cross PCIe (lrc_scan_poses_compact)
             fr = scene.scan_poses_compact(np.asarray(lidar.pose, dtype=np.float64)[None],
-                                          self._direction_table(lidar.intrinsics), lidar.intrinsics.max_range,
+                                          self._resident_table(lidar.intrinsics), lidar.intrinsics.max_range,
                                           want=("point3", "incident_deg"))
             if fr["total"] > 0:
                 return fr["point3"], fr["incident_deg"]
@@ -240,7 +256,7 @@ class RaycastEngineHIP(RaycastEngineBase):
         poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 4, 4)
         if not hasattr(intrinsics, "horizontal_res") or hasattr(intrinsics, "swing_amplitude"):
             raise ValueError("sensor has no pose-independent direction table")
-        return self.scene_for(mesh).scan_poses_compact(poses, self._direction_table(intrinsics),
+        return self.scene_for(mesh).scan_poses_compact(poses, self._resident_table(intrinsics),
                                                        intrinsics.max_range, want=want,
                                                        grid=self._grid_of(intrinsics, len(poses)))
 

@@ -234,6 +234,9 @@ class DirectionTable:
         check(self._lib.lrc_table_create(ctx._h, _ptr(d), len(d), C.byref(h)), "lrc_table_create")
         self._h, self.n = h, len(d)
 
+    def __len__(self):
+        return self.n
+
     def close(self):
         if getattr(self, "_h", None):
             if getattr(self.ctx, "_h", None):
@@ -434,9 +437,14 @@ class Scene:
         """Pose-batched scan straight to the kept rows of every pose (lrc_scan_poses_compact): dict of (K, ...)
         arrays over page-locked memory + ``counts`` (P,) int64 + ``total`` K.  Frame p = rows
         [counts[:p].sum(), counts[:p+1].sum()).  ``grid`` = (lines, width, az0, az_step) of a table that is a
-        (scan line x azimuth) grid selects the packet kernel (lrc_scan_grid_compact): same bytes, faster."""
+        (scan line x azimuth) grid selects the packet kernel (lrc_scan_grid_compact): same bytes (a measured alternative,
+        slower on the benchmark scenes).  ``dirs`` may be a DirectionTable handle (uploaded once, lrc_scan_table_compact)."""
         poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 16)
         if isinstance(dirs, DirectionTable):          # resident table: nothing to upload
+            if not dirs._h:
+                raise ValueError("direction table handle is closed")
+            if dirs.ctx is not self.ctx:
+                raise ValueError("direction table belongs to another context (device)")
             P, N = poses.shape[0], dirs.n
             fr, counts, bufs, cap = self._frames_begin(P, P * N, want, capacity)
             total = C.c_uint64(0)

@@ -669,3 +669,37 @@ def test_dual_axis_default_path_to_frames(engine):
         assert fr["range_origin_mean"][i] == np.mean(r) and fr["range_origin_std"][i] == np.std(r)
         a = fr["incident_deg"][ends[i] - fr["counts"][i]:ends[i]]
         assert fr["incident_mean"][i] == np.mean(a) and fr["incident_std"][i] == np.std(a)
+
+
+def test_resident_direction_table_handle(engine):
+    """lrc_table_create + lrc_scan_table_compact (the sensor's table uploaded once) against lrc_scan_poses_compact (table
+    from host memory every call): the same frames bit for bit, statistics included; the handle survives many calls,
+    a closed handle is refused loudly, and the engine keeps one per sensor."""
+    import lidarcast
+    from lidar import IndoorLidar
+    from lidarcast import synth
+    mesh = synth.make_room(size=(5, 4, 2.6), num_boxes=5, seed=4, cell=0.05)
+    k = sensor_small(lines=8, width=256)
+    dirs = IndoorLidar(intrinsics=k, pose=np.eye(4)).sensor_directions()
+    poses = np.stack([pose(0.8 + 0.5 * i, 2.0, 1.2, 0.3 * i) for i in range(7)])
+    scene = engine.scene_for(mesh)
+    want = ("point3", "sem", "incident_deg", "index", "range_origin", "range_origin_stats", "incident_stats")
+    a = scene.scan_poses_compact(poses, dirs, k.max_range, want=want)
+    table = lidarcast.DirectionTable(scene.ctx, dirs)
+    assert len(table) == len(dirs)
+    for _ in range(3):
+        b = scene.scan_poses_compact(poses, table, k.max_range, want=want)
+        assert b["total"] == a["total"] > 0 and np.array_equal(a["counts"], b["counts"])
+        for key in ("point3", "incident_deg", "range_origin", "range_origin_mean", "range_origin_std", "incident_mean",
+                    "incident_std"):
+            assert_bit_equal(a[key], b[key])
+        assert np.array_equal(a["sem"], b["sem"]) and np.array_equal(a["index"], b["index"])
+    one = scene.scan_poses_compact(poses[2:3], table, k.max_range, want=("point3",))
+    lo = int(a["counts"][:2].sum())
+    assert_bit_equal(one["point3"], a["point3"][lo:lo + int(a["counts"][2])])
+    table.close()
+    table.close()                                                   # idempotent
+    with pytest.raises((ValueError, RuntimeError)):
+        scene.scan_poses_compact(poses, table, k.max_range, want=want)
+    t1 = engine._resident_table(k)
+    assert engine._resident_table(k) is t1 and len(t1) == len(dirs)  # one upload per sensor

@@ -86,6 +86,8 @@ typedef struct lrc_scene_info {
     double   upload_ms;
     float    bounds_lo[3];
     float    bounds_hi[3];
+    uint32_t quantised_nodes;  /* 1: the trace kernels walk the 32-byte quantised node images of this tree   */
+    float    leaf_inflation;   /* mean half perimeter of a leaf box on the 15-bit grid / of its float32 box  */
 } lrc_scene_info;
 
 #define LRC_MAX_BVH_DEPTH 32

@@ -108,6 +108,12 @@ struct lrc_scene {
     uint32_t* d_slot_label = nullptr;
     float4* d_prim_plane = nullptr;   // per caller's triangle row: (v0, label bits), (Ng, 0): lrc_cloud_from_prims_dev
     float4* d_slot_sphere = nullptr;  // per leaf slot: centre of the triangle's box + bounding radius (sector_kernel)
+    // quantised node images of the SAME tree ("32-byte nodes"): child boxes on a 15-bit grid
+    // per axis, rounded outward by >= 1 cell.  d_nodes_q: 32 B per node for the per-lane fetches; d_nodes_n: the same
+    // boxes as normalised float32 (64 B per node) for the scalar fetches.  NULL when the grid does not fit the scene.
+    uint4* d_nodes_q = nullptr;
+    float4* d_nodes_n = nullptr;
+    float qbase[3] = {0, 0, 0}, qW[3] = {1, 1, 1}, qinvW[3] = {1, 1, 1};
     const lrc_grid* cur_grid = nullptr;   // set around a grid scan (launch_trace gen == 3)
     lrc_scene_info info{};
     lrc_scan_options opts{};          // sticky opt-in options (lrc_scene_set_options)
@@ -142,6 +148,9 @@ struct TraceParams {
     const uint32_t* slot_label;
     const float4* prim_plane;  // per caller's triangle row: (v0, label bits), (Ng, 0)
     uint32_t num_nodes;
+    const uint4* nodes_q;      // QN kernels: 32-byte quantised nodes (per-lane fetches) ...
+    const float4* nodes_n;     // ... and the same boxes as normalised float32 (scalar fetches)
+    float qbase[3], qW[3], qinvW[3];   // normalised coordinate n = (x - qbase) * qinvW in [2, 4); qW = 1 / qinvW = 2^k
     // inputs
     const float* rays6;        // explicit rays (GEN = false)
     const uint64_t* seg_offsets;   // explicit rays in S segments (poses): (S+1) ray offsets, or NULL
@@ -344,9 +353,13 @@ __device__ __forceinline__ void write_back(const TraceParams& p, uint64_t gid, u
 
 constexpr int kStatsWords = 5;   // node steps, triangle tests, wave-uniform node steps, dead node steps, pad-clause rejections
 
+template <int I> struct IntTag { static constexpr int value = I; };
+
 // GEN: 0 = explicit rays, 1 = pose x direction table, 2 = pose x per-ray scan angles (dual-axis sensor, opt-in)
-template <int GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false>
-__global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
+// QN: walk the quantised node images (32-byte nodes for the per-lane fetches); a wave with a
+//     ray outside the bound the quantisation margin is proven for walks the float32 world-space nodes instead
+template <int GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false, bool QN = false>
+__global__ __launch_bounds__(kTBlock, (QN && !STATS && GEN == 1 && LEAFW == 1) ? 8 : 1) void trace_kernel(const TraceParams p) {
     extern __shared__ int s_stack[];   // [stack depth][kTBlock]: one column per lane, conflict free
     const uint32_t tid = threadIdx.x;
     const uint64_t gid = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * kTBlock + tid;
@@ -356,15 +369,18 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
     V3 o, d;
     double cx, cy, cz;
     bool live = true;          // false: not cast at all (dropped by the sensor, or a non-finite ray)
+    uint32_t pose32 = 0;
     if (GEN == 1) {
         const uint64_t pose = gid / p.rays_per_pose;
         const uint64_t i = gid - pose * p.rays_per_pose;
         gen_ray(p.poses16, p.dirs3, pose, i, o, d, cx, cy, cz);
+        pose32 = (uint32_t)pose;
     } else if (GEN == 2) {
         const uint64_t pose = gid / p.rays_per_pose;
         const double2 a = ((const double2*)p.angles2)[gid];
         gen_ray_angles(p.poses16, pose, a.x, a.y, o, d, cx, cy, cz);
         if (p.keep_mask) live = p.keep_mask[gid] != 0;
+        pose32 = (uint32_t)pose;
     } else {
         const float* r = p.rays6 + gid * 6;
         o.x = r[0]; o.y = r[1]; o.z = r[2];
@@ -372,8 +388,7 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
         if (p.keep_mask) live = p.keep_mask[gid] != 0;          // rays the sensor dropped: never cast
         if (!p.seg_offsets && p.seg_centers3) {
             // explicit rays of several poses at a FIXED stride (rays_per_pose each, dropped ones masked): pose = gid / N
-            const double* c = p.seg_centers3 + (size_t)(gid / p.rays_per_pose) * 3;
-            cx = c[0]; cy = c[1]; cz = c[2];
+            pose32 = (uint32_t)(gid / p.rays_per_pose);
         } else if (p.seg_offsets) {
             // rays of several poses back to back: find this ray's pose (largest s with off[s] <= gid)
             uint32_t lo = 0, hi = p.num_segments;
@@ -381,33 +396,55 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
                 const uint32_t mid = (lo + hi) >> 1;
                 if (p.seg_offsets[mid] <= gid) lo = mid; else hi = mid;
             }
-            const double* c = p.seg_centers3 + (size_t)lo * 3;
-            cx = c[0]; cy = c[1]; cz = c[2];
-        } else if (p.has_center) { cx = p.cx; cy = p.cy; cz = p.cz; }
-        else { cx = (double)o.x; cy = (double)o.y; cz = (double)o.z; }
+            pose32 = lo;
+        }
     }
 
     // ---- closest hit ----
-    const RaySlab sl = make_slab(o, d);
     float tbest = __builtin_inff();
     uint32_t best_slot = 0xFFFFFFFFu;
     uint32_t best_prim = 0xFFFFFFFFu;   // loaded lazily, only to break exact ties
 
     uint32_t st_nodes = 0, st_tris = 0, st_uni = 0, st_dead = 0, st_pad = 0;   // STATS build only (lrc_debug_scan_stats)
     live = live & finite_ray(o, d);
-    if (p.num_nodes && live) {
+
+    // The traversal, once per node image: Q = false walks the float32 world-space nodes with the ray's world-space slab
+    // constants; Q = true walks the quantised images with the slab constants in normalised coordinates.  Which boxes
+    // are visited differs (the quantised boxes are a little larger), what is found does not: every box test is
+    // conservative with respect to the hit definition (lrc_device.h), the closest hit is order independent.
+    // qtag 0: float32 world-space nodes.  1: quantised images; all rays of the wave point into one direction octant, so
+    // the plane selectors are wave-uniform and live in SGPRs.
+    auto traverse = [&](auto qtag) {
+        constexpr int QM = decltype(qtag)::value;
+        constexpr bool Q = QM != 0;
+        RaySlab sl;
+        uint32_t sel_nx = 0, sel_ny = 0, sel_nz = 0, sel_fx = 0, sel_fy = 0, sel_fz = 0;
+        if (Q) {
+            // normalised coordinates: n = (x - base) / W per axis, W a power of two (scaling by it is exact)
+            const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
+            sl.ix = ix * p.qW[0]; sl.iy = iy * p.qW[1]; sl.iz = iz * p.qW[2];
+            sl.ox = ((o.x - p.qbase[0]) * p.qinvW[0]) * sl.ix;
+            sl.oy = ((o.y - p.qbase[1]) * p.qinvW[1]) * sl.iy;
+            sl.oz = ((o.z - p.qbase[2]) * p.qinvW[2]) * sl.iz;
+            // v_perm_b32 selectors: the plane the rays enter / leave through on each axis, picked by the sign of the
+            // direction (for ix > 0 fma(lo, ix, -ox) <= fma(hi, ix, -ox) by monotone rounding, so picking by sign IS
+            // the min / max of slab_interval, bit for bit)
+            constexpr uint32_t kLo = 0x0701000Cu, kHi = 0x0703020Cu;   // {0x40, half word, 0x00}
+            const uint32_t oct = (uint32_t)__builtin_amdgcn_readfirstlane((int)sign_octant(d));
+            sel_nx = (oct & 1u) ? kHi : kLo; sel_fx = (oct & 1u) ? kLo : kHi;
+            sel_ny = (oct & 2u) ? kHi : kLo; sel_fy = (oct & 2u) ? kLo : kHi;
+            sel_nz = (oct & 4u) ? kHi : kLo; sel_fz = (oct & 4u) ? kLo : kHi;
+        } else {
+            sl = make_slab(o, d);
+        }
         int sp = 0;
         int ref = 0;   // root
-        // one inner-node step: test both child boxes, descend into the nearer hit child, push the other;
-        // nothing hit -> pop, or (stack empty) continue with the empty leaf so that the outer loop ends
-        auto step = [&](const F4 q0, const F4 q1, const F4 q2, const F4 q3) {
+        // descend into the nearer hit child, push the other; nothing hit -> pop, or (stack empty) continue with the
+        // empty leaf so that the outer loop ends
+        auto choose = [&](float n0, float f0, float n1, float f1, int r0, int r1) {
             if (STATS) st_nodes += 1u;
-            float n0, f0, n1, f1;
-            slab_interval(sl, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, n0, f0);
-            slab_interval(sl, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, n1, f1);
             const bool h0 = (n0 <= f0) & (n0 <= tbest);
             const bool h1 = (n1 <= f1) & (n1 <= tbest);
-            const int r0 = __float_as_int(q3.x), r1 = __float_as_int(q3.y);
             if (h0 & h1) {
                 const bool first0 = n0 <= n1;
                 s_stack[sp * kTBlock + tid] = first0 ? r1 : r0;
@@ -425,6 +462,30 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
                 --sp;
                 ref = s_stack[sp * kTBlock + tid];
             }
+        };
+        // one inner-node step on a float32 node (world space, or the normalised image on the scalar path)
+        auto step = [&](const F4 q0, const F4 q1, const F4 q2, const F4 q3) {
+            float n0, f0, n1, f1;
+            slab_interval(sl, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, n0, f0);
+            slab_interval(sl, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, n1, f1);
+            choose(n0, f0, n1, f1, __float_as_int(q3.x), __float_as_int(q3.y));
+        };
+        // one inner-node step on a 32-byte quantised node: per child (lo|hi << 16) x, y, z and the reference
+        auto step_q = [&](const uint4 a, const uint4 b) {
+            auto plane = [](uint32_t w, uint32_t sel) { return __uint_as_float(__builtin_amdgcn_perm(0x40000000u, w, sel)); };
+            auto interval = [&](const uint4 c, float& tn, float& tf) {
+                const float nx = fma_(plane(c.x, sel_nx), sl.ix, -sl.ox), fx = fma_(plane(c.x, sel_fx), sl.ix, -sl.ox);
+                const float ny = fma_(plane(c.y, sel_ny), sl.iy, -sl.oy), fy = fma_(plane(c.y, sel_fy), sl.iy, -sl.oy);
+                const float nz = fma_(plane(c.z, sel_nz), sl.iz, -sl.oz), fz = fma_(plane(c.z, sel_fz), sl.iz, -sl.oz);
+                const float n = max2(max2(nx, ny), max2(nz, 0.0f));
+                const float f = min2(min2(fx, fy), fz);
+                tn = fma_(n, kPadRelLo, -kPadAbs);
+                tf = fma_(f, kPadRelHi, kPadAbs);
+            };
+            float n0, f0, n1, f1;
+            interval(a, n0, f0);
+            interval(b, n1, f1);
+            choose(n0, f0, n1, f1, (int)a.w, (int)b.w);
         };
         // one leaf: test its 1..4 triangles, keep the lexicographically smallest (t, triangle row)
         auto leaf = [&](const int lref) {
@@ -447,7 +508,25 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
                         const float4 a = ra[j], b = rb[j], c = rc[j];
                         const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
                         float t;
-                        if (tri_hit<STATS>(o, d, sl, v0, v1, v2, ng, t, &st_pad)) {
+                        bool hit;
+                        if (Q) {
+                            // the definition's box clause is in world coordinates: its slab constants are rebuilt from
+                            // the normalised ones (ix = ix' / W exactly; ox = o * ix as make_slab forms it) for the
+                            // few triangles that pass the Moeller-Trumbore conditions
+                            hit = tri_hit_with<STATS>(o, d, [&] {
+                                RaySlab w;
+                                float k0 = p.qinvW[0], k1 = p.qinvW[1], k2 = p.qinvW[2];
+                                // opaque to the optimiser: otherwise the six constants are hoisted out of the loop and
+                                // held in registers for its whole duration (8 waves per SIMD need <= 64 VGPRs)
+                                asm volatile("" : "+s"(k0), "+s"(k1), "+s"(k2));
+                                w.ix = sl.ix * k0; w.iy = sl.iy * k1; w.iz = sl.iz * k2;
+                                w.ox = o.x * w.ix; w.oy = o.y * w.iy; w.oz = o.z * w.iz;
+                                return w;
+                            }, v0, v1, v2, ng, t, &st_pad);
+                        } else {
+                            hit = tri_hit<STATS>(o, d, sl, v0, v1, v2, ng, t, &st_pad);
+                        }
+                        if (hit) {
                             if (t < tbest) {
                                 tbest = t; best_slot = slot; best_prim = 0xFFFFFFFFu;
                             } else if (t == tbest) {
@@ -460,6 +539,15 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
                 }
             }
         };
+        auto fetch_step = [&]() {         // per-lane fetch of node `ref`
+            if (Q) {
+                const uint4* n = p.nodes_q + (size_t)ref * 2;
+                step_q(n[0], n[1]);
+            } else {
+                const F4* n = (const F4*)(p.nodes + (size_t)ref * 4);
+                step(n[0], n[1], n[2], n[3]);
+            }
+        };
         while (true) {
             // descend inner nodes
             int pending = ~0;   // SPEC: one postponed leaf (empty = ~0)
@@ -467,19 +555,17 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
                 if (UNI) {
                     // Neighbouring rays walk the top of the tree in lock step.  When every active lane
                     // of the wave wants the same node, fetch it once through the scalar cache into
-                    // SGPRs (s_load) instead of 64 identical 64-byte vector loads through the L1.
+                    // SGPRs (s_load) instead of 64 identical vector loads through the L1.
                     const int uref = __builtin_amdgcn_readfirstlane(ref);
                     if (__builtin_amdgcn_ballot_w64(ref != uref) == 0ull) {
                         if (STATS) st_uni += 1u;
-                        const float4* n = p.nodes + (size_t)uref * 4;
+                        const float4* n = (Q ? p.nodes_n : p.nodes) + (size_t)uref * 4;
                         step(ld_uniform(n), ld_uniform(n + 1), ld_uniform(n + 2), ld_uniform(n + 3));
                     } else {
-                        const F4* n = (const F4*)(p.nodes + (size_t)ref * 4);
-                        step(n[0], n[1], n[2], n[3]);
+                        fetch_step();
                     }
                 } else {
-                    const F4* n = (const F4*)(p.nodes + (size_t)ref * 4);
-                    step(n[0], n[1], n[2], n[3]);
+                    fetch_step();
                 }
                 if (SPEC) {
                     // speculative traversal: park the first leaf and keep descending from the stack, so
@@ -497,9 +583,40 @@ __global__ __launch_bounds__(kTBlock) void trace_kernel(const TraceParams p) {
             --sp;
             ref = s_stack[sp * kTBlock + tid];
         }
+    };
+    if (p.num_nodes) {
+        if (QN) {
+            // outside this bound the margin of the quantised boxes is not proven to cover the difference
+            // between the two slab arithmetics: such a wave walks the float32 nodes
+            auto far1 = [](float oa, float da, float base, float W) {
+                return !(__builtin_fabsf(oa - base) <= 6.f * W) | !(__builtin_fabsf(oa) <= 12.f * W) |
+                       !(__builtin_fabsf(da) <= 0x1p60f);
+            };
+            const bool far = live & (far1(o.x, d.x, p.qbase[0], p.qW[0]) | far1(o.y, d.y, p.qbase[1], p.qW[1]) |
+                                     far1(o.z, d.z, p.qbase[2], p.qW[2]));
+            const uint32_t oct = sign_octant(d);
+            const uint32_t oct0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)oct);     // of the first live lane
+            // a wave whose rays point into different octants (it straddles an axis direction) walks the float32 nodes too
+            if (__builtin_amdgcn_ballot_w64(far | (live & (oct != oct0))) != 0ull) { if (live) traverse(IntTag<0>{}); }
+            else if (live) traverse(IntTag<1>{});
+        } else if (live) {
+            traverse(IntTag<0>{});
+        }
     }
 
     // ---- fused write-back ----
+    if (GEN != 0) {
+        // the range-filter centre (the pose's translation, float64) is fetched again here instead of being held in six
+        // registers through the traversal; the pointer is made opaque so that the fetch is not merged with gen_ray's
+        const double* M = p.poses16;
+        asm volatile("" : "+s"(M));
+        M += (size_t)pose32 * 16;
+        cx = M[3]; cy = M[7]; cz = M[11];
+    } else if (p.seg_centers3) {
+        const double* c = p.seg_centers3 + (size_t)pose32 * 3;      // the centre of this ray's pose (segment)
+        cx = c[0]; cy = c[1]; cz = c[2];
+    } else if (p.has_center) { cx = p.cx; cy = p.cy; cz = p.cz; }
+    else { cx = (double)o.x; cy = (double)o.y; cz = (double)o.z; }
     write_back<GEN != 0>(p, gid, tid, o, d, cx, cy, cz, tbest, best_slot);
     if (STATS) {
         if (p.stats) {
@@ -946,8 +1063,80 @@ int lrc_scene_destroy(lrc_scene* s) {
     if (s->d_slot_label) (void)hipFree(s->d_slot_label);
     if (s->d_prim_plane) (void)hipFree(s->d_prim_plane);
     if (s->d_slot_sphere) (void)hipFree(s->d_slot_sphere);
+    if (s->d_nodes_q) (void)hipFree(s->d_nodes_q);
+    if (s->d_nodes_n) (void)hipFree(s->d_nodes_n);
     delete s;
     return LRC_OK;
+}
+
+// ---- quantised node images ----------------------------------------------------------------
+// Per axis a power-of-two width W and a float32 base b put the scene into normalised coordinates n = (x - b) / W in
+// [2, 4): every float32 there has the exponent byte 0x40, so a 15-bit grid index q IS the float 0x40000000 | q << 8
+// = 2 + q * 2^-14 and one v_perm_b32 rebuilds it from a packed half word.  A child box is rounded outward to the grid
+// with a margin of 1/16 cell: the allowance for the difference between the slab arithmetic in normalised coordinates
+// and the definition's arithmetic in world coordinates, which is below 2^-24 (4|o - b| + |o| + 8 W) in box space, i.e.
+// below 2.7e-6 W = 0.044 cell for a ray origin o with |o - b| <= 6 W and |o| <= 12 W (the scene itself is [b + 2 W,
+// b + 4 W), so this holds one scene width around the scene); the kernel sends every other ray through the float32
+// world-space nodes.  Returns false (no images; the float32 nodes are used) when a scene does not fit.
+constexpr double kQnodeMaxInflation = 1.05;
+constexpr double kQnodeMargin = 1.0 / 16;     // cells; see the bound in DESIGN.md section 4.1
+static bool build_qnodes(const lrc::HostBVH& h, float base[3], float W[3], float invW[3], std::vector<uint32_t>& q8,
+                         std::vector<float>& n16, double* leaf_inflation) {
+    const uint64_t N = h.num_nodes;
+    if (N == 0) return false;
+    double Wd[3], bd[3];
+    for (int a = 0; a < 3; ++a) {
+        const double lo = h.bounds_lo[a], hi = h.bounds_hi[a];
+        if (!(hi >= lo)) return false;
+        int k = -20;                                                 // W = 2^k, 2^-20 <= W <= 2^16
+        while (k <= 16 && 2.0 * std::ldexp(1.0, k) * (1.0 - 1.0 / 1024) < (hi - lo)) ++k;
+        if (k > 16) return false;
+        Wd[a] = std::ldexp(1.0, k);
+        const double cell = Wd[a] / 16384.0;
+        const double b = lo - 8.0 * cell - 2.0 * Wd[a];
+        float bf = (float)b;
+        if ((double)bf > b) bf = std::nextafter(bf, -INFINITY);
+        bd[a] = (double)bf;
+        if (!(std::fabs(bd[a]) <= 8.0 * Wd[a])) return false;        // a scene this far from the world origin: all rays "far"
+        base[a] = bf; W[a] = (float)Wd[a]; invW[a] = (float)(1.0 / Wd[a]);
+    }
+    q8.assign(N * 8, 0u);
+    n16.assign(N * 16, 0.0f);
+    auto decode = [](uint32_t q) { uint32_t u = 0x40000000u | (q << 8); float f; std::memcpy(&f, &u, 4); return f; };
+    double infl_sum = 0.0;       // over leaf boxes: half perimeter of the quantised box / of the float32 box
+    uint64_t infl_n = 0;
+    for (uint64_t i = 0; i < N; ++i) {
+        const float* nd = h.nodes.data() + i * 16;
+        uint32_t* qo = q8.data() + i * 8;
+        float* no = n16.data() + i * 16;
+        for (int c = 0; c < 2; ++c) {
+            const float* lo = nd + c * 6, *hi = nd + c * 6 + 3;
+            uint32_t ql[3], qh[3];
+            for (int a = 0; a < 3; ++a) {
+                const double nl = ((double)lo[a] - bd[a]) / Wd[a], nh = ((double)hi[a] - bd[a]) / Wd[a];   // exact
+                const double fl = std::floor((nl - 2.0) * 16384.0 - kQnodeMargin), fh = std::ceil((nh - 2.0) * 16384.0 + kQnodeMargin);
+                if (!(fl >= 0.0) || !(fh <= 32767.0) || !(fl <= fh)) return false;
+                ql[a] = (uint32_t)fl; qh[a] = (uint32_t)fh;
+                qo[c * 4 + a] = ql[a] | (qh[a] << 16);
+                no[c * 6 + a] = decode(ql[a]);
+                no[c * 6 + 3 + a] = decode(qh[a]);
+            }
+            std::memcpy(&qo[c * 4 + 3], &nd[12 + c], 4);             // the child reference
+            int32_t ref;
+            std::memcpy(&ref, &nd[12 + c], 4);
+            if (ref < 0 && ref != ~0) {
+                double hw = 0.0, hq = 0.0;
+                for (int a = 0; a < 3; ++a) {
+                    hw += (double)hi[a] - (double)lo[a];
+                    hq += (double)(qh[a] - ql[a]) * (Wd[a] / 16384.0);
+                }
+                if (hw > 0.0) { infl_sum += hq / hw; infl_n += 1; }
+            }
+        }
+        no[12] = nd[12]; no[13] = nd[13];
+    }
+    *leaf_inflation = infl_n ? infl_sum / (double)infl_n : 1.0;
+    return true;
 }
 
 int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32_t* tris3, uint64_t T,
@@ -1050,6 +1239,31 @@ int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32
         g_err = keep;
         return rc;
     }
+    {
+        static const auto qn_env = [] { const char* e = std::getenv("LRC_QNODES"); return e ? std::atoi(e) : 1; };
+        std::vector<uint32_t> q8;
+        std::vector<float> n16;
+        // LRC_QNODES: 0 = float32 nodes only, 1 (default) = quantised images when the grid is fine enough for the
+        // scene's triangles, 2 = whenever the grid fits.  The grid has 2^15 cells along each axis of the scene; where
+        // the cells are not small against the leaf boxes (a very large scene of small triangles) the widened boxes
+        // cost more triangle tests than the smaller nodes save (measured: DESIGN.md section 4.1).
+        double infl = 1.0;
+        const int mode = qn_env();
+        if (mode != 0 && build_qnodes(h, s->qbase, s->qW, s->qinvW, q8, n16, &infl) && (mode == 2 || infl <= kQnodeMaxInflation)) {
+            if ((rc = upload((void**)&s->d_nodes_q, q8.data(), q8.size() * 4)) ||
+                (rc = upload((void**)&s->d_nodes_n, n16.data(), n16.size() * 4))) {
+                std::string keep = g_err;
+                lrc_scene_destroy(s);
+                g_err = keep;
+                return rc;
+            }
+        }
+        in.quantised_nodes = s->d_nodes_q ? 1u : 0u;
+        in.leaf_inflation = (float)infl;
+        if (std::getenv("LRC_QNODES_VERBOSE"))
+            std::fprintf(stderr, "[qnodes] leaf box inflation %.3f, W = %g %g %g -> %s\n", infl, (double)s->qW[0],
+                         (double)s->qW[1], (double)s->qW[2], s->d_nodes_q ? "quantised images" : "float32 nodes");
+    }
     auto t2 = std::chrono::steady_clock::now();
     in.upload_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
     *out_scene = s;
@@ -1095,6 +1309,10 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
     p.slot_label = s->d_slot_label;
     p.prim_plane = s->d_prim_plane;
     p.num_nodes = (uint32_t)s->info.num_nodes;
+    p.nodes_q = s->d_nodes_q;
+    p.nodes_n = s->d_nodes_n;
+    for (int a = 0; a < 3; ++a) { p.qbase[a] = s->qbase[a]; p.qW[a] = s->qW[a]; p.qinvW[a] = s->qinvW[a]; }
+    const bool qn = s->d_nodes_q != nullptr;
     p.min_range = s->opts.min_range;
     p.incident_mode = s->opts.incident_mode;
     if (!p.range_noise && s->opts.range_noise) {      // device entry points: the pointer is a device pointer
@@ -1116,7 +1334,10 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
 #define LRC_PICK(G)                                                                  \
     do {                                                                             \
         if (spec) { if (leafw == 2) LRC_LAUNCH(G, 2, true, true); else LRC_LAUNCH(G, 1, true, true); }        \
-        else if (uni) { if (leafw == 2) LRC_LAUNCH(G, 2, true, false); else LRC_LAUNCH(G, 1, true, false); }  \
+        else if (uni) { if (leafw == 2 && qn) hipLaunchKernelGGL((trace_kernel<G, 2, true, false, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p); \
+                        else if (leafw == 2) LRC_LAUNCH(G, 2, true, false);                                    \
+                        else if (qn) hipLaunchKernelGGL((trace_kernel<G, 1, true, false, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p); \
+                        else LRC_LAUNCH(G, 1, true, false); }  \
         else { if (leafw == 2) LRC_LAUNCH(G, 2, false, false); else LRC_LAUNCH(G, 1, false, false); }         \
     } while (0)
     static const int no_sector = [] { const char* e = std::getenv("LRC_SECTOR"); return e ? std::atoi(e) == 0 : 0; }();
@@ -1179,11 +1400,14 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
         return LRC_OK;
     }
     if (stats) {   // diagnostic build: per-ray traversal counters (lrc_debug_scan_stats)
-        if (gen == 1) hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
+        if (gen == 1 && qn) hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
+        else if (gen == 1) hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
+        else if (gen == 0 && qn) hipLaunchKernelGGL((trace_kernel<0, 1, true, false, true, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
         else if (gen == 0) hipLaunchKernelGGL((trace_kernel<0, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
         else return fail(LRC_ERR_INVALID_ARG, "traversal statistics are not available for the scan-angle generator");
     } else if (gen == 1) LRC_PICK(1);
-    else if (gen == 2) LRC_LAUNCH(2, 1, true, false);
+    else if (gen == 2) { if (qn) hipLaunchKernelGGL((trace_kernel<2, 1, true, false, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
+                         else LRC_LAUNCH(2, 1, true, false); }
     else LRC_PICK(0);
 #undef LRC_PICK
 #undef LRC_LAUNCH
@@ -1199,9 +1423,14 @@ int lrc_scene_get_occupancy(const lrc_scene* s, int* waves_per_cu, int* vgprs, i
     const uint32_t depth = s->info.max_depth < 1 ? 1 : s->info.max_depth;
     const size_t lds = (size_t)depth * kTBlock * sizeof(int);
     int blocks = 0;
-    LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<1, 1, true, false, false>, kTBlock, lds));
     hipFuncAttributes attr;
-    LRC_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trace_kernel<1, 1, true, false, false>)));
+    if (s->d_nodes_q) {
+        LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<1, 1, true, false, false, true>, kTBlock, lds));
+        LRC_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trace_kernel<1, 1, true, false, false, true>)));
+    } else {
+        LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<1, 1, true, false, false>, kTBlock, lds));
+        LRC_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trace_kernel<1, 1, true, false, false>)));
+    }
     if (waves_per_cu) *waves_per_cu = blocks * (kTBlock / 64);
     if (vgprs) *vgprs = attr.numRegs;
     if (lds_bytes) *lds_bytes = (int)lds;

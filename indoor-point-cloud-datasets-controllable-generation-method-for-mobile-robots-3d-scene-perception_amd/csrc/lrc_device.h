@@ -55,6 +55,12 @@ LRC_DI RaySlab make_slab(V3 o, V3 d) {
     return r;
 }
 
+// which of lo / hi a ray enters a box through, per axis: bit a set = negative 1/d (safe_inv keeps the sign of d, of a
+// zero component too)
+LRC_DI uint32_t sign_octant(V3 d) {
+    return (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
+}
+
 // Padded entry/exit parameters of the ray against the box [lo,hi].
 // Monotone in lo/hi, hence the interval of a box contains the interval of every box inside it.
 LRC_DI void slab_interval(const RaySlab& s, float lox, float loy, float loz, float hix, float hiy,
@@ -92,6 +98,37 @@ LRC_DI bool tri_hit(V3 o, V3 d, const RaySlab& s, V3 v0, V3 v1, V3 v2, V3 ng, fl
     bool ok = (den != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= aden) & (tt > 0.0f);
     if (!ok) return false;
     float t = tt / aden;
+    float lox = min2(min2(v0.x, v1.x), v2.x), hix = max2(max2(v0.x, v1.x), v2.x);
+    float loy = min2(min2(v0.y, v1.y), v2.y), hiy = max2(max2(v0.y, v1.y), v2.y);
+    float loz = min2(min2(v0.z, v1.z), v2.z), hiz = max2(max2(v0.z, v1.z), v2.z);
+    float tn, tf;
+    slab_interval(s, lox, loy, loz, hix, hiy, hiz, tn, tf);
+    if (!((tn <= t) & (t <= tf) & (t < __builtin_inff()))) {
+        if (DIAG) { if (t < __builtin_inff()) *pad_rej += 1u; }
+        return false;
+    }
+    t_out = t;
+    return true;
+}
+
+// tri_hit with the ray's slab constants produced on demand (slab() is called only for a triangle that passes the
+// Moeller-Trumbore conditions, which is when the box clause needs them): identical conditions and arithmetic.
+template <bool DIAG = false, class SlabFn>
+LRC_DI bool tri_hit_with(V3 o, V3 d, SlabFn slab, V3 v0, V3 v1, V3 v2, V3 ng, float& t_out, uint32_t* pad_rej = nullptr) {
+    V3 e1 = sub3(v0, v1);
+    V3 e2 = sub3(v2, v0);
+    V3 c = sub3(v0, o);
+    V3 r = cross3(c, d);
+    float den = dot3(ng, d);
+    float aden = __builtin_fabsf(den);
+    uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+    float u = xorsign(dot3(r, e2), sgn);
+    float v = xorsign(dot3(r, e1), sgn);
+    float tt = xorsign(dot3(ng, c), sgn);
+    bool ok = (den != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= aden) & (tt > 0.0f);
+    if (!ok) return false;
+    float t = tt / aden;
+    const RaySlab s = slab();
     float lox = min2(min2(v0.x, v1.x), v2.x), hix = max2(max2(v0.x, v1.x), v2.x);
     float loy = min2(min2(v0.y, v1.y), v2.y), hiy = max2(max2(v0.y, v1.y), v2.y);
     float loz = min2(min2(v0.z, v1.z), v2.z), hiz = max2(max2(v0.z, v1.z), v2.z);

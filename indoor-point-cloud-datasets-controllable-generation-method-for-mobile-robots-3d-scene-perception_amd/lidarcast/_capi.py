@@ -49,7 +49,8 @@ class LrcSceneInfo(C.Structure):
                 ("num_nodes", C.c_uint64), ("num_leaves", C.c_uint64), ("num_slots", C.c_uint64),
                 ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32),
                 ("device_bytes", C.c_uint64), ("build_ms", C.c_double), ("upload_ms", C.c_double),
-                ("bounds_lo", C.c_float * 3), ("bounds_hi", C.c_float * 3)]
+                ("bounds_lo", C.c_float * 3), ("bounds_hi", C.c_float * 3),
+                ("quantised_nodes", C.c_uint32), ("leaf_inflation", C.c_float)]
 
 
 class LrcScanOptions(C.Structure):

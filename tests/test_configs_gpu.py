@@ -703,3 +703,66 @@ def test_resident_direction_table_handle(engine):
         scene.scan_poses_compact(poses, table, k.max_range, want=want)
     t1 = engine._resident_table(k)
     assert engine._resident_table(k) is t1 and len(t1) == len(dirs)  # one upload per sensor
+
+
+def test_quantised_node_images_and_their_fallbacks(engine, monkeypatch):
+    """The 32-byte quantised node images against the definition (oracle, brute force): a room the
+    grid fits (images in use), rays the margin is proven for, rays it is not (origins many scene widths away, waves
+    that mix both, huge direction vectors), waves that straddle an axis direction (mixed octants), and a scene too
+    far from the world origin for the grid (float32 nodes only).  Same bytes every time; float32-only scene equal too."""
+    import lidarcast
+    from lidarcast import synth
+    from oracle.c_oracle import OracleMesh
+    mesh = synth.make_room(size=(5, 4, 2.6), num_boxes=6, seed=12, cell=0.04)
+    om = OracleMesh(mesh.vertices, mesh.triangles).build()
+    rng = np.random.default_rng(3)
+    n = 64 * 300
+    o = rng.uniform([0.3, 0.3, 0.3], [4.7, 3.7, 2.3], (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    aim = rng.uniform([0.5, 0.5, 0.2], [4.5, 3.5, 2.4], (n, 3))
+    # waves 0..99 in the room; 100..149 from 20..5000 m away aimed at the room; 150..199 alternate lane by lane;
+    # 200..249 axis-parallel directions and directions of length 1e25; 250..299 one octant per wave (sorted signs)
+    far_o = aim + d * rng.uniform(20.0, 5000.0, (n, 1))
+    sl = slice(64 * 100, 64 * 150)
+    o[sl] = far_o[sl]; d[sl] = -d[sl]
+    sl = slice(64 * 150, 64 * 200)
+    alt = (np.arange(64 * 50) % 2).astype(bool)
+    o[sl][alt] = far_o[sl][alt]; d[sl][alt] = -d[sl][alt]
+    sl = slice(64 * 200, 64 * 225)
+    ax = np.eye(3)[rng.integers(0, 3, 64 * 25)] * rng.choice([-1.0, 1.0], (64 * 25, 1))
+    d[sl] = ax
+    d[64 * 225:64 * 250] *= 1e25
+    sl = slice(64 * 250, 64 * 300)
+    d[sl] = np.abs(d[sl]) * np.repeat(rng.choice([-1.0, 1.0], (50, 3)), 64, axis=0)
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    t_ref, prim_ref = om.cast(rays)
+    assert 0.5 < np.isfinite(t_ref).mean() <= 1.0 and np.isfinite(t_ref[64 * 100:64 * 150]).mean() > 0.5
+    pick = rng.choice(n, 2500, replace=False)            # and the definition itself, no tree at all
+    t_bf, prim_bf = om.brute(rays[pick])
+    assert_bit_equal(t_bf, t_ref[pick])
+    assert np.array_equal(prim_bf, prim_ref[pick])
+    scene = lidarcast.Scene(engine.ctx, mesh.vertices, mesh.triangles)
+    assert scene.info["quantised_nodes"] == 1 and 1.0 < scene.info["leaf_inflation"] < 1.05
+    out = scene.cast(rays, want=("t", "prim"))
+    assert_bit_equal(out["t"], t_ref)
+    assert np.array_equal(out["prim"], prim_ref)
+    monkeypatch.setenv("LRC_QNODES", "0")
+    plain = lidarcast.Scene(engine.ctx, mesh.vertices, mesh.triangles)
+    assert plain.info["quantised_nodes"] == 0
+    out0 = plain.cast(rays, want=("t", "prim"))
+    assert_bit_equal(out0["t"], t_ref)
+    assert np.array_equal(out0["prim"], prim_ref)
+    monkeypatch.delenv("LRC_QNODES")
+    # the same room 3 km from the world origin: float32 coordinates there are 0.25 mm apart; the grid is not used
+    shift = np.array([3000.0, -2000.0, 100.0])
+    v_far = (mesh.vertices + shift).astype(np.float32)
+    distant = lidarcast.Scene(engine.ctx, v_far, mesh.triangles)
+    assert distant.info["quantised_nodes"] == 0
+    rays_far = rays[:64 * 100].copy()
+    rays_far[:, :3] = (rays_far[:, :3].astype(np.float64) + shift).astype(np.float32)
+    om_far = OracleMesh(v_far, mesh.triangles).build()
+    t2, p2 = om_far.cast(rays_far)
+    out2 = distant.cast(rays_far, want=("t", "prim"))
+    assert_bit_equal(out2["t"], t2)
+    assert np.array_equal(out2["prim"], p2)

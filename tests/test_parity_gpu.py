@@ -957,7 +957,8 @@ def test_export_labels_from_annotated_cloud(tmp_path, engine):
 
 def test_kernel_variants_are_bit_identical():
     """Traversal order / fetch strategy / leaf size must not change a single output byte:
-    the scalar-fetch, leaf-pair, speculative-postponement and small-leaf variants against the default."""
+    the scalar-fetch, leaf-pair, speculative-postponement, small-leaf and node-image (float32 / quantised) variants
+    against the default."""
     import subprocess
     import sys
     from conftest import REPO
@@ -966,7 +967,9 @@ def test_kernel_variants_are_bit_identical():
     for name, env in {"default": {}, "no_scalar_fetch": {"LRC_UNIFORM": "0"}, "leaf_pairs": {"LRC_LEAFW": "2"},
                       "speculative": {"LRC_SPEC": "1"}, "leaves_of_2": {"LRC_MAX_LEAF": "2"},
                       "leaves_of_1": {"LRC_MAX_LEAF": "1"}, "refill_2": {"LRC_REFILL": "2"},
-                      "refill_4": {"LRC_REFILL": "4"}, "refill_2_w7": {"LRC_REFILL": "2", "LRC_REFILL_W": "7"}}.items():
+                      "refill_4": {"LRC_REFILL": "4"}, "refill_2_w7": {"LRC_REFILL": "2", "LRC_REFILL_W": "7"},
+                      "float32_nodes": {"LRC_QNODES": "0"}, "quantised_nodes_forced": {"LRC_QNODES": "2"},
+                      "quantised_leaf_pairs": {"LRC_QNODES": "2", "LRC_LEAFW": "2"}}.items():
         e = dict(os.environ)
         e.update(env)
         r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=300, env=e, check=True)

@@ -545,7 +545,18 @@ __global__ __launch_bounds__(kTBlock, (QN && !STATS && GEN == 1 && LEAFW == 1) ?
                 step_q(n[0], n[1]);
             } else {
                 const F4* n = (const F4*)(p.nodes + (size_t)ref * 4);
+#ifdef LRC_EXP_EXTRA_NODE_LOADS      // measurement build only (tools/extra_load_experiment.sh): N more 16-byte loads of this line
+                typedef float xv4f __attribute__((ext_vector_type(4)));
+                xv4f sink[LRC_EXP_EXTRA_NODE_LOADS];
+#pragma unroll
+                for (int x = 0; x < LRC_EXP_EXTRA_NODE_LOADS; ++x)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink[x]) : "v"(n + (x & 3)));
+#endif
                 step(n[0], n[1], n[2], n[3]);
+#ifdef LRC_EXP_EXTRA_NODE_LOADS
+#pragma unroll
+                for (int x = 0; x < LRC_EXP_EXTRA_NODE_LOADS; ++x) asm volatile("s_waitcnt vmcnt(0)" :: "v"(sink[x]));
+#endif
             }
         };
         while (true) {

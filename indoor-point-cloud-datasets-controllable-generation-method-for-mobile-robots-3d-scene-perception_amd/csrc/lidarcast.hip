@@ -109,10 +109,15 @@ struct lrc_scene {
     float4* d_prim_plane = nullptr;   // per caller's triangle row: (v0, label bits), (Ng, 0): lrc_cloud_from_prims_dev
     float4* d_slot_sphere = nullptr;  // per leaf slot: centre of the triangle's box + bounding radius (sector_kernel)
     // quantised node images of the SAME tree ("32-byte nodes"): child boxes on a 15-bit grid
-    // per axis, rounded outward by >= 1 cell.  d_nodes_q: 32 B per node for the per-lane fetches; d_nodes_n: the same
+    // per axis, rounded outward (margin 1/16 cell).  d_nodes_q: 32 B per node for the per-lane fetches; d_nodes_n: the same
     // boxes as normalised float32 (64 B per node) for the scalar fetches.  NULL when the grid does not fit the scene.
     uint4* d_nodes_q = nullptr;
     float4* d_nodes_n = nullptr;
+    // the same tree collapsed to four children per node (every second level removed), on the same grid:
+    // d_nodes_q4 64 B per node (per child lo|hi<<16 x, y, z + reference), d_nodes_n4 128 B (per child lo, hi, ref, pad)
+    uint4* d_nodes_q4 = nullptr;
+    float4* d_nodes_n4 = nullptr;
+    uint64_t num_nodes4 = 0;
     float qbase[3] = {0, 0, 0}, qW[3] = {1, 1, 1}, qinvW[3] = {1, 1, 1};
     const lrc_grid* cur_grid = nullptr;   // set around a grid scan (launch_trace gen == 3)
     lrc_scene_info info{};
@@ -150,6 +155,9 @@ struct TraceParams {
     uint32_t num_nodes;
     const uint4* nodes_q;      // QN kernels: 32-byte quantised nodes (per-lane fetches) ...
     const float4* nodes_n;     // ... and the same boxes as normalised float32 (scalar fetches)
+    const uint4* nodes_q4;     // QN = 2: the tree collapsed to four children per node, 64 B per node ...
+    const float4* nodes_n4;    // ... and 128 B per node as normalised float32
+    uint32_t stack_cap;        // entries of the per-lane LDS stack
     float qbase[3], qW[3], qinvW[3];   // normalised coordinate n = (x - qbase) * qinvW in [2, 4); qW = 1 / qinvW = 2^k
     // inputs
     const float* rays6;        // explicit rays (GEN = false)
@@ -356,10 +364,11 @@ constexpr int kStatsWords = 5;   // node steps, triangle tests, wave-uniform nod
 template <int I> struct IntTag { static constexpr int value = I; };
 
 // GEN: 0 = explicit rays, 1 = pose x direction table, 2 = pose x per-ray scan angles (dual-axis sensor, opt-in)
-// QN: walk the quantised node images (32-byte nodes for the per-lane fetches); a wave with a
-//     ray outside the bound the quantisation margin is proven for walks the float32 world-space nodes instead
-template <int GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false, bool QN = false>
-__global__ __launch_bounds__(kTBlock, (QN && !STATS && GEN == 1 && LEAFW == 1) ? 8 : 1) void trace_kernel(const TraceParams p) {
+// QN: 1 = walk the quantised node images (32-byte nodes for the per-lane fetches), 2 = walk their
+//     four-wide collapse (64-byte nodes, half the steps); a wave with a ray outside the bound the quantisation margin is
+//     proven for walks the float32 world-space nodes instead
+template <int GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false, int QN = 0>
+__global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW == 1) ? 8 : 1) void trace_kernel(const TraceParams p) {
     extern __shared__ int s_stack[];   // [stack depth][kTBlock]: one column per lane, conflict free
     const uint32_t tid = threadIdx.x;
     const uint64_t gid = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * kTBlock + tid;
@@ -413,7 +422,8 @@ __global__ __launch_bounds__(kTBlock, (QN && !STATS && GEN == 1 && LEAFW == 1) ?
     // are visited differs (the quantised boxes are a little larger), what is found does not: every box test is
     // conservative with respect to the hit definition (lrc_device.h), the closest hit is order independent.
     // qtag 0: float32 world-space nodes.  1: quantised images; all rays of the wave point into one direction octant, so
-    // the plane selectors are wave-uniform and live in SGPRs.
+    // the plane selectors are wave-uniform and live in SGPRs.  2: the same on the four-wide collapse of the tree.
+    bool ovf = false;          // qtag 2: this lane's stack would not have held a step's pushes; the ray is redone on qtag 0
     auto traverse = [&](auto qtag) {
         constexpr int QM = decltype(qtag)::value;
         constexpr bool Q = QM != 0;
@@ -487,6 +497,61 @@ __global__ __launch_bounds__(kTBlock, (QN && !STATS && GEN == 1 && LEAFW == 1) ?
             interval(b, n1, f1);
             choose(n0, f0, n1, f1, (int)a.w, (int)b.w);
         };
+        // four-wide step: descend into the nearest hit child, push the other hit children; nothing hit -> pop
+        auto choose4 = [&](float t0, float f0, float t1, float f1, float t2, float f2, float t3, float f3,
+                           int r0, int r1, int r2, int r3) {
+            if (STATS) st_nodes += 1u;
+            const bool h0 = (t0 <= f0) & (t0 <= tbest), h1 = (t1 <= f1) & (t1 <= tbest);
+            const bool h2 = (t2 <= f2) & (t2 <= tbest), h3 = (t3 <= f3) & (t3 <= tbest);
+            const float inf = __builtin_inff();
+            const float d0 = h0 ? t0 : inf, d1 = h1 ? t1 : inf, d2 = h2 ? t2 : inf, d3 = h3 ? t3 : inf;
+            const float dm = min2(min2(d0, d1), min2(d2, d3));
+            if (dm < inf) {
+                if (sp + 3 > (int)p.stack_cap) {      // cannot happen on a tree whose depth the stack was sized for
+                    ovf = true; ref = ~0; sp = 0;     // ... unless three children stay pending level after level
+                } else {
+                    const int near = d0 == dm ? 0 : d1 == dm ? 1 : d2 == dm ? 2 : 3;
+                    if (h3 & (near != 3)) { s_stack[sp * kTBlock + tid] = r3; ++sp; }
+                    if (h2 & (near != 2)) { s_stack[sp * kTBlock + tid] = r2; ++sp; }
+                    if (h1 & (near != 1)) { s_stack[sp * kTBlock + tid] = r1; ++sp; }
+                    if (h0 & (near != 0)) { s_stack[sp * kTBlock + tid] = r0; ++sp; }
+                    ref = near == 0 ? r0 : near == 1 ? r1 : near == 2 ? r2 : r3;
+                }
+            } else if (sp == 0) {
+                if (STATS) st_dead += 1u;
+                ref = ~0;
+            } else {
+                if (STATS) st_dead += 1u;
+                --sp;
+                ref = s_stack[sp * kTBlock + tid];
+            }
+        };
+        auto step_q4 = [&](const uint4 a, const uint4 b, const uint4 c, const uint4 e) {
+            auto plane = [](uint32_t w, uint32_t sel) { return __uint_as_float(__builtin_amdgcn_perm(0x40000000u, w, sel)); };
+            auto interval = [&](const uint4 k, float& tn, float& tf) {
+                const float nx = fma_(plane(k.x, sel_nx), sl.ix, -sl.ox), fx = fma_(plane(k.x, sel_fx), sl.ix, -sl.ox);
+                const float ny = fma_(plane(k.y, sel_ny), sl.iy, -sl.oy), fy = fma_(plane(k.y, sel_fy), sl.iy, -sl.oy);
+                const float nz = fma_(plane(k.z, sel_nz), sl.iz, -sl.oz), fz = fma_(plane(k.z, sel_fz), sl.iz, -sl.oz);
+                const float n = max2(max2(nx, ny), max2(nz, 0.0f));
+                const float f = min2(min2(fx, fy), fz);
+                tn = fma_(n, kPadRelLo, -kPadAbs);
+                tf = fma_(f, kPadRelHi, kPadAbs);
+            };
+            float t0, f0, t1, f1, t2, f2, t3, f3;
+            interval(a, t0, f0); interval(b, t1, f1); interval(c, t2, f2); interval(e, t3, f3);
+            choose4(t0, f0, t1, f1, t2, f2, t3, f3, (int)a.w, (int)b.w, (int)c.w, (int)e.w);
+        };
+        // the same on a wave-uniform node of the normalised float32 image (128 B: per child lo, hi, reference, pad)
+        auto step_n4 = [&](const F4 a0, const F4 a1, const F4 b0, const F4 b1, const F4 c0, const F4 c1, const F4 e0,
+                           const F4 e1) {
+            float t0, f0, t1, f1, t2, f2, t3, f3;
+            slab_interval(sl, a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, t0, f0);
+            slab_interval(sl, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, t1, f1);
+            slab_interval(sl, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, t2, f2);
+            slab_interval(sl, e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, t3, f3);
+            choose4(t0, f0, t1, f1, t2, f2, t3, f3, __float_as_int(a1.z), __float_as_int(b1.z), __float_as_int(c1.z),
+                    __float_as_int(e1.z));
+        };
         // one leaf: test its 1..4 triangles, keep the lexicographically smallest (t, triangle row)
         auto leaf = [&](const int lref) {
             const uint32_t enc = (uint32_t)(~lref);
@@ -540,8 +605,21 @@ __global__ __launch_bounds__(kTBlock, (QN && !STATS && GEN == 1 && LEAFW == 1) ?
             }
         };
         auto fetch_step = [&]() {         // per-lane fetch of node `ref`
-            if (Q) {
+            if (QM == 2) {
+                const uint4* n = p.nodes_q4 + (size_t)ref * 4;
+                step_q4(n[0], n[1], n[2], n[3]);
+            } else if (Q) {
                 const uint4* n = p.nodes_q + (size_t)ref * 2;
+#ifdef LRC_EXP_TIMING      // measurement build only (tools/trav_timing.py): cycles a wave waits for a per-lane node fetch
+                if (STATS) {
+                    const uint64_t c0 = __builtin_amdgcn_s_memtime();
+                    const uint4 a = n[0], b = n[1];
+                    asm volatile("s_waitcnt vmcnt(0)" :: "v"(a.x), "v"(b.x));
+                    st_uni += (uint32_t)(__builtin_amdgcn_s_memtime() - c0);
+                    step_q(a, b);
+                    return;
+                }
+#endif
                 step_q(n[0], n[1]);
             } else {
                 const F4* n = (const F4*)(p.nodes + (size_t)ref * 4);
@@ -570,8 +648,14 @@ __global__ __launch_bounds__(kTBlock, (QN && !STATS && GEN == 1 && LEAFW == 1) ?
                     const int uref = __builtin_amdgcn_readfirstlane(ref);
                     if (__builtin_amdgcn_ballot_w64(ref != uref) == 0ull) {
                         if (STATS) st_uni += 1u;
-                        const float4* n = (Q ? p.nodes_n : p.nodes) + (size_t)uref * 4;
-                        step(ld_uniform(n), ld_uniform(n + 1), ld_uniform(n + 2), ld_uniform(n + 3));
+                        if (QM == 2) {
+                            const float4* n = p.nodes_n4 + (size_t)uref * 8;
+                            step_n4(ld_uniform(n), ld_uniform(n + 1), ld_uniform(n + 2), ld_uniform(n + 3),
+                                    ld_uniform(n + 4), ld_uniform(n + 5), ld_uniform(n + 6), ld_uniform(n + 7));
+                        } else {
+                            const float4* n = (Q ? p.nodes_n : p.nodes) + (size_t)uref * 4;
+                            step(ld_uniform(n), ld_uniform(n + 1), ld_uniform(n + 2), ld_uniform(n + 3));
+                        }
                     } else {
                         fetch_step();
                     }
@@ -595,6 +679,9 @@ __global__ __launch_bounds__(kTBlock, (QN && !STATS && GEN == 1 && LEAFW == 1) ?
             ref = s_stack[sp * kTBlock + tid];
         }
     };
+#ifdef LRC_EXP_TIMING
+    const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+#endif
     if (p.num_nodes) {
         if (QN) {
             // outside this bound the margin of the quantised boxes is not proven to cover the difference
@@ -609,12 +696,27 @@ __global__ __launch_bounds__(kTBlock, (QN && !STATS && GEN == 1 && LEAFW == 1) ?
             const uint32_t oct0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)oct);     // of the first live lane
             // a wave whose rays point into different octants (it straddles an axis direction) walks the float32 nodes too
             if (__builtin_amdgcn_ballot_w64(far | (live & (oct != oct0))) != 0ull) { if (live) traverse(IntTag<0>{}); }
-            else if (live) traverse(IntTag<1>{});
+            else if (live) {
+                if (QN == 2) {
+                    traverse(IntTag<2>{});
+                    if (__builtin_amdgcn_ballot_w64(ovf) != 0ull) {
+                        if (ovf) {
+                            tbest = __builtin_inff(); best_slot = 0xFFFFFFFFu; best_prim = 0xFFFFFFFFu;
+                            traverse(IntTag<0>{});
+                        }
+                    }
+                } else {
+                    traverse(IntTag<1>{});
+                }
+            }
         } else if (live) {
             traverse(IntTag<0>{});
         }
     }
 
+#ifdef LRC_EXP_TIMING
+    if (STATS) { st_dead = (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin); st_pad = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live)); }
+#endif
     // ---- fused write-back ----
     if (GEN != 0) {
         // the range-filter centre (the pose's translation, float64) is fetched again here instead of being held in six
@@ -1076,6 +1178,8 @@ int lrc_scene_destroy(lrc_scene* s) {
     if (s->d_slot_sphere) (void)hipFree(s->d_slot_sphere);
     if (s->d_nodes_q) (void)hipFree(s->d_nodes_q);
     if (s->d_nodes_n) (void)hipFree(s->d_nodes_n);
+    if (s->d_nodes_q4) (void)hipFree(s->d_nodes_q4);
+    if (s->d_nodes_n4) (void)hipFree(s->d_nodes_n4);
     delete s;
     return LRC_OK;
 }
@@ -1091,29 +1195,46 @@ int lrc_scene_destroy(lrc_scene* s) {
 // world-space nodes.  Returns false (no images; the float32 nodes are used) when a scene does not fit.
 constexpr double kQnodeMaxInflation = 1.05;
 constexpr double kQnodeMargin = 1.0 / 16;     // cells; see the bound in DESIGN.md section 4.1
-static bool build_qnodes(const lrc::HostBVH& h, float base[3], float W[3], float invW[3], std::vector<uint32_t>& q8,
-                         std::vector<float>& n16, double* leaf_inflation) {
-    const uint64_t N = h.num_nodes;
-    if (N == 0) return false;
-    double Wd[3], bd[3];
+struct QGrid { double Wd[3], bd[3]; };
+
+static bool make_qgrid(const lrc::HostBVH& h, float base[3], float W[3], float invW[3], QGrid& g) {
+    if (h.num_nodes == 0) return false;
     for (int a = 0; a < 3; ++a) {
         const double lo = h.bounds_lo[a], hi = h.bounds_hi[a];
         if (!(hi >= lo)) return false;
         int k = -20;                                                 // W = 2^k, 2^-20 <= W <= 2^16
         while (k <= 16 && 2.0 * std::ldexp(1.0, k) * (1.0 - 1.0 / 1024) < (hi - lo)) ++k;
         if (k > 16) return false;
-        Wd[a] = std::ldexp(1.0, k);
-        const double cell = Wd[a] / 16384.0;
-        const double b = lo - 8.0 * cell - 2.0 * Wd[a];
+        g.Wd[a] = std::ldexp(1.0, k);
+        const double cell = g.Wd[a] / 16384.0;
+        const double b = lo - 8.0 * cell - 2.0 * g.Wd[a];
         float bf = (float)b;
         if ((double)bf > b) bf = std::nextafter(bf, -INFINITY);
-        bd[a] = (double)bf;
-        if (!(std::fabs(bd[a]) <= 8.0 * Wd[a])) return false;        // a scene this far from the world origin: all rays "far"
-        base[a] = bf; W[a] = (float)Wd[a]; invW[a] = (float)(1.0 / Wd[a]);
+        g.bd[a] = (double)bf;
+        if (!(std::fabs(g.bd[a]) <= 8.0 * g.Wd[a])) return false;    // a scene this far from the world origin: all rays "far"
+        base[a] = bf; W[a] = (float)g.Wd[a]; invW[a] = (float)(1.0 / g.Wd[a]);
     }
+    return true;
+}
+
+// grid indices of a float32 box, rounded outward with the margin; false: outside the grid
+static bool qbox(const QGrid& g, const float* lo, const float* hi, uint32_t ql[3], uint32_t qh[3]) {
+    for (int a = 0; a < 3; ++a) {
+        const double nl = ((double)lo[a] - g.bd[a]) / g.Wd[a], nh = ((double)hi[a] - g.bd[a]) / g.Wd[a];   // exact
+        const double fl = std::floor((nl - 2.0) * 16384.0 - kQnodeMargin), fh = std::ceil((nh - 2.0) * 16384.0 + kQnodeMargin);
+        if (!(fl >= 0.0) || !(fh <= 32767.0) || !(fl <= fh)) return false;
+        ql[a] = (uint32_t)fl; qh[a] = (uint32_t)fh;
+    }
+    return true;
+}
+
+static float qdecode(uint32_t q) { uint32_t u = 0x40000000u | (q << 8); float f; std::memcpy(&f, &u, 4); return f; }
+
+static bool build_qnodes(const lrc::HostBVH& h, const QGrid& g, std::vector<uint32_t>& q8, std::vector<float>& n16,
+                         double* leaf_inflation) {
+    const uint64_t N = h.num_nodes;
     q8.assign(N * 8, 0u);
     n16.assign(N * 16, 0.0f);
-    auto decode = [](uint32_t q) { uint32_t u = 0x40000000u | (q << 8); float f; std::memcpy(&f, &u, 4); return f; };
     double infl_sum = 0.0;       // over leaf boxes: half perimeter of the quantised box / of the float32 box
     uint64_t infl_n = 0;
     for (uint64_t i = 0; i < N; ++i) {
@@ -1123,14 +1244,11 @@ static bool build_qnodes(const lrc::HostBVH& h, float base[3], float W[3], float
         for (int c = 0; c < 2; ++c) {
             const float* lo = nd + c * 6, *hi = nd + c * 6 + 3;
             uint32_t ql[3], qh[3];
+            if (!qbox(g, lo, hi, ql, qh)) return false;
             for (int a = 0; a < 3; ++a) {
-                const double nl = ((double)lo[a] - bd[a]) / Wd[a], nh = ((double)hi[a] - bd[a]) / Wd[a];   // exact
-                const double fl = std::floor((nl - 2.0) * 16384.0 - kQnodeMargin), fh = std::ceil((nh - 2.0) * 16384.0 + kQnodeMargin);
-                if (!(fl >= 0.0) || !(fh <= 32767.0) || !(fl <= fh)) return false;
-                ql[a] = (uint32_t)fl; qh[a] = (uint32_t)fh;
                 qo[c * 4 + a] = ql[a] | (qh[a] << 16);
-                no[c * 6 + a] = decode(ql[a]);
-                no[c * 6 + 3 + a] = decode(qh[a]);
+                no[c * 6 + a] = qdecode(ql[a]);
+                no[c * 6 + 3 + a] = qdecode(qh[a]);
             }
             std::memcpy(&qo[c * 4 + 3], &nd[12 + c], 4);             // the child reference
             int32_t ref;
@@ -1139,7 +1257,7 @@ static bool build_qnodes(const lrc::HostBVH& h, float base[3], float W[3], float
                 double hw = 0.0, hq = 0.0;
                 for (int a = 0; a < 3; ++a) {
                     hw += (double)hi[a] - (double)lo[a];
-                    hq += (double)(qh[a] - ql[a]) * (Wd[a] / 16384.0);
+                    hq += (double)(qh[a] - ql[a]) * (g.Wd[a] / 16384.0);
                 }
                 if (hw > 0.0) { infl_sum += hq / hw; infl_n += 1; }
             }
@@ -1147,6 +1265,67 @@ static bool build_qnodes(const lrc::HostBVH& h, float base[3], float W[3], float
         no[12] = nd[12]; no[13] = nd[13];
     }
     *leaf_inflation = infl_n ? infl_sum / (double)infl_n : 1.0;
+    return true;
+}
+
+// The binary tree collapsed to four children per node: a node keeps the children of its inner children (its grandchildren)
+// and its leaf children; every second level disappears.  Slots [0, 1] come from child 0, [2, 3] from child 1; an unused
+// slot holds an inverted box (never hit) and the empty leaf.  References of inner slots index THIS array (breadth-first
+// numbering), leaf references are unchanged.  Same grid, same outward rounding as build_qnodes.
+static bool build_q4nodes(const lrc::HostBVH& h, const QGrid& g, std::vector<uint32_t>& q16, std::vector<float>& n32,
+                          uint64_t* num4) {
+    const uint64_t N = h.num_nodes;
+    std::vector<uint32_t> order;              // binary node of every 4-wide node, in 4-wide numbering
+    order.reserve(N / 2 + 1);
+    order.push_back(0u);
+    q16.clear(); n32.clear();
+    q16.reserve((N / 2 + 1) * 16); n32.reserve((N / 2 + 1) * 32);
+    const int32_t empty_ref = ~0;
+    for (size_t i4 = 0; i4 < order.size(); ++i4) {
+        const float* X = h.nodes.data() + (size_t)order[i4] * 16;
+        struct Slot { const float* lo; const float* hi; int32_t ref; bool inner; } slot[4];
+        for (int c = 0; c < 2; ++c) {
+            int32_t ref;
+            std::memcpy(&ref, &X[12 + c], 4);
+            Slot& s0 = slot[2 * c]; Slot& s1 = slot[2 * c + 1];
+            if (ref >= 0) {                   // inner child: its two children take the two slots
+                const float* Y = h.nodes.data() + (size_t)ref * 16;
+                for (int cc = 0; cc < 2; ++cc) {
+                    Slot& t = cc ? s1 : s0;
+                    t.lo = Y + cc * 6; t.hi = Y + cc * 6 + 3;
+                    std::memcpy(&t.ref, &Y[12 + cc], 4);
+                    t.inner = t.ref >= 0;
+                }
+            } else {                          // leaf child (or the empty leaf): stays, the other slot is unused
+                s0.lo = X + c * 6; s0.hi = X + c * 6 + 3; s0.ref = ref; s0.inner = false;
+                s1.lo = nullptr; s1.hi = nullptr; s1.ref = empty_ref; s1.inner = false;
+            }
+        }
+        const size_t qo = q16.size(), no = n32.size();
+        q16.resize(qo + 16, 0u);
+        n32.resize(no + 32, 0.0f);
+        for (int k = 0; k < 4; ++k) {
+            uint32_t ql[3] = {32767u, 32767u, 32767u}, qh[3] = {0u, 0u, 0u};          // inverted: never hit
+            int32_t ref = slot[k].ref;
+            if (slot[k].lo) {
+                if (!qbox(g, slot[k].lo, slot[k].hi, ql, qh)) return false;
+                if (slot[k].inner) {
+                    if (order.size() >= 0x7FFFFFFFull) return false;
+                    const int32_t child4 = (int32_t)order.size();
+                    order.push_back((uint32_t)ref);
+                    ref = child4;
+                }
+            }
+            for (int a = 0; a < 3; ++a) {
+                q16[qo + k * 4 + a] = ql[a] | (qh[a] << 16);
+                n32[no + k * 8 + a] = qdecode(ql[a]);
+                n32[no + k * 8 + 3 + a] = qdecode(qh[a]);
+            }
+            std::memcpy(&q16[qo + k * 4 + 3], &ref, 4);
+            std::memcpy(&n32[no + k * 8 + 6], &ref, 4);
+        }
+    }
+    *num4 = order.size();
     return true;
 }
 
@@ -1252,17 +1431,23 @@ int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32
     }
     {
         static const auto qn_env = [] { const char* e = std::getenv("LRC_QNODES"); return e ? std::atoi(e) : 1; };
-        std::vector<uint32_t> q8;
-        std::vector<float> n16;
+        std::vector<uint32_t> q8, q16;
+        std::vector<float> n16, n32;
         // LRC_QNODES: 0 = float32 nodes only, 1 (default) = quantised images when the grid is fine enough for the
         // scene's triangles, 2 = whenever the grid fits.  The grid has 2^15 cells along each axis of the scene; where
         // the cells are not small against the leaf boxes (a very large scene of small triangles) the widened boxes
         // cost more triangle tests than the smaller nodes save (measured: DESIGN.md section 4.1).
         double infl = 1.0;
         const int mode = qn_env();
-        if (mode != 0 && build_qnodes(h, s->qbase, s->qW, s->qinvW, q8, n16, &infl) && (mode == 2 || infl <= kQnodeMaxInflation)) {
+        QGrid g;
+        if (mode != 0 && make_qgrid(h, s->qbase, s->qW, s->qinvW, g) && build_qnodes(h, g, q8, n16, &infl) &&
+            (mode >= 2 || infl <= kQnodeMaxInflation)) {
+            const char* we = std::getenv("LRC_WIDE");
+            if (we && std::atoi(we) != 0 && !build_q4nodes(h, g, q16, n32, &s->num_nodes4)) { q16.clear(); n32.clear(); }
             if ((rc = upload((void**)&s->d_nodes_q, q8.data(), q8.size() * 4)) ||
-                (rc = upload((void**)&s->d_nodes_n, n16.data(), n16.size() * 4))) {
+                (rc = upload((void**)&s->d_nodes_n, n16.data(), n16.size() * 4)) ||
+                (rc = upload((void**)&s->d_nodes_q4, q16.data(), q16.size() * 4)) ||
+                (rc = upload((void**)&s->d_nodes_n4, n32.data(), n32.size() * 4))) {
                 std::string keep = g_err;
                 lrc_scene_destroy(s);
                 g_err = keep;
@@ -1322,6 +1507,8 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
     p.num_nodes = (uint32_t)s->info.num_nodes;
     p.nodes_q = s->d_nodes_q;
     p.nodes_n = s->d_nodes_n;
+    p.nodes_q4 = s->d_nodes_q4;
+    p.nodes_n4 = s->d_nodes_n4;
     for (int a = 0; a < 3; ++a) { p.qbase[a] = s->qbase[a]; p.qW[a] = s->qW[a]; p.qinvW[a] = s->qinvW[a]; }
     const bool qn = s->d_nodes_q != nullptr;
     p.min_range = s->opts.min_range;
@@ -1337,6 +1524,9 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
     // stack entries needed = deepest leaf depth (one pending sibling per inner level above it)
     const uint32_t depth = s->info.max_depth < 1 ? 1 : s->info.max_depth;
     const size_t lds = (size_t)depth * kTBlock * sizeof(int);
+    p.stack_cap = depth;
+    // measured alternative: the four-wide collapse; built and walked only under LRC_WIDE=1
+    const int wide = s->d_nodes_q4 != nullptr;
     static const int leafw = [] { const char* e = std::getenv("LRC_LEAFW"); return e ? std::atoi(e) : 1; }();
     static const int uni = [] { const char* e = std::getenv("LRC_UNIFORM"); return e ? std::atoi(e) : 1; }();
     static const int spec = [] { const char* e = std::getenv("LRC_SPEC"); return e ? std::atoi(e) : 0; }();
@@ -1345,9 +1535,10 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
 #define LRC_PICK(G)                                                                  \
     do {                                                                             \
         if (spec) { if (leafw == 2) LRC_LAUNCH(G, 2, true, true); else LRC_LAUNCH(G, 1, true, true); }        \
-        else if (uni) { if (leafw == 2 && qn) hipLaunchKernelGGL((trace_kernel<G, 2, true, false, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p); \
+        else if (uni) { if (leafw == 2 && qn) hipLaunchKernelGGL((trace_kernel<G, 2, true, false, false, 1>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p); \
                         else if (leafw == 2) LRC_LAUNCH(G, 2, true, false);                                    \
-                        else if (qn) hipLaunchKernelGGL((trace_kernel<G, 1, true, false, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p); \
+                        else if (qn && wide) hipLaunchKernelGGL((trace_kernel<G, 1, true, false, false, 2>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p); \
+                        else if (qn) hipLaunchKernelGGL((trace_kernel<G, 1, true, false, false, 1>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p); \
                         else LRC_LAUNCH(G, 1, true, false); }  \
         else { if (leafw == 2) LRC_LAUNCH(G, 2, false, false); else LRC_LAUNCH(G, 1, false, false); }         \
     } while (0)
@@ -1411,13 +1602,14 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
         return LRC_OK;
     }
     if (stats) {   // diagnostic build: per-ray traversal counters (lrc_debug_scan_stats)
-        if (gen == 1 && qn) hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
+        if (gen == 1 && qn && wide) hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true, 2>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
+        else if (gen == 1 && qn) hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true, 1>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
         else if (gen == 1) hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
-        else if (gen == 0 && qn) hipLaunchKernelGGL((trace_kernel<0, 1, true, false, true, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
+        else if (gen == 0 && qn) hipLaunchKernelGGL((trace_kernel<0, 1, true, false, true, 1>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
         else if (gen == 0) hipLaunchKernelGGL((trace_kernel<0, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
         else return fail(LRC_ERR_INVALID_ARG, "traversal statistics are not available for the scan-angle generator");
     } else if (gen == 1) LRC_PICK(1);
-    else if (gen == 2) { if (qn) hipLaunchKernelGGL((trace_kernel<2, 1, true, false, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
+    else if (gen == 2) { if (qn) hipLaunchKernelGGL((trace_kernel<2, 1, true, false, false, 1>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
                          else LRC_LAUNCH(2, 1, true, false); }
     else LRC_PICK(0);
 #undef LRC_PICK
@@ -1436,8 +1628,8 @@ int lrc_scene_get_occupancy(const lrc_scene* s, int* waves_per_cu, int* vgprs, i
     int blocks = 0;
     hipFuncAttributes attr;
     if (s->d_nodes_q) {
-        LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<1, 1, true, false, false, true>, kTBlock, lds));
-        LRC_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trace_kernel<1, 1, true, false, false, true>)));
+        LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<1, 1, true, false, false, 1>, kTBlock, lds));
+        LRC_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trace_kernel<1, 1, true, false, false, 1>)));
     } else {
         LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<1, 1, true, false, false>, kTBlock, lds));
         LRC_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trace_kernel<1, 1, true, false, false>)));

@@ -969,7 +969,8 @@ def test_kernel_variants_are_bit_identical():
                       "leaves_of_1": {"LRC_MAX_LEAF": "1"}, "refill_2": {"LRC_REFILL": "2"},
                       "refill_4": {"LRC_REFILL": "4"}, "refill_2_w7": {"LRC_REFILL": "2", "LRC_REFILL_W": "7"},
                       "float32_nodes": {"LRC_QNODES": "0"}, "quantised_nodes_forced": {"LRC_QNODES": "2"},
-                      "quantised_leaf_pairs": {"LRC_QNODES": "2", "LRC_LEAFW": "2"}}.items():
+                      "quantised_leaf_pairs": {"LRC_QNODES": "2", "LRC_LEAFW": "2"},
+                      "four_wide_nodes": {"LRC_QNODES": "2", "LRC_WIDE": "1"}}.items():
         e = dict(os.environ)
         e.update(env)
         r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=300, env=e, check=True)

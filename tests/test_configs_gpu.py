@@ -766,3 +766,57 @@ def test_quantised_node_images_and_their_fallbacks(engine, monkeypatch):
     out2 = distant.cast(rays_far, want=("t", "prim"))
     assert_bit_equal(out2["t"], t2)
     assert np.array_equal(out2["prim"], p2)
+
+
+def test_quantised_images_on_random_scenes(engine, monkeypatch):
+    """Quantised node images against the float32 nodes of the same tree, bit for bit, over scenes of very different
+    shape -- triangle soups from millimetres to hundreds of metres, offset from the world origin by up to three scene
+    widths, flat in one axis, a single triangle -- with origins inside, on the faces of and around the scene's box and
+    directions that graze box planes (axis-parallel, one component 0 or -0, denormal-small components)."""
+    import lidarcast
+    from oracle.c_oracle import OracleMesh
+    rng = np.random.default_rng(2024)
+    used = 0
+    for case in range(12):
+        scale = 10.0 ** rng.uniform(-2.0, 2.5)
+        T = int(rng.integers(1, 4000)) if case else 1
+        centre = rng.uniform(-1.0, 1.0, 3) * scale * rng.choice([0.0, 0.5, 3.0])
+        ext = np.array([1.0, rng.uniform(0.05, 1.0), rng.uniform(0.0 if case == 3 else 0.01, 1.0)]) * scale
+        c = rng.uniform(-0.5, 0.5, (T, 1, 3)) * ext
+        tri = (centre + c + rng.normal(scale=0.03 * scale, size=(T, 3, 3)) * (ext > 0)).astype(np.float32)
+        v, f = tri.reshape(-1, 3), np.arange(3 * T, dtype=np.int32).reshape(-1, 3)
+        lo, hi = v.min(0).astype(np.float64), v.max(0).astype(np.float64)
+        n = 64 * 400
+        o = rng.uniform(lo - 0.3 * (hi - lo) - 1e-3 * scale, hi + 0.3 * (hi - lo) + 1e-3 * scale, (n, 3))
+        onface = rng.random(n) < 0.2                       # origins exactly on a face of the scene's box
+        ax = rng.integers(0, 3, n)
+        o[onface, ax[onface]] = np.where(rng.random(onface.sum()) < 0.5, lo[ax[onface]], hi[ax[onface]])
+        target = v[rng.integers(0, len(v), n)].astype(np.float64) + rng.normal(scale=0.01 * scale, size=(n, 3))
+        d = target - o
+        kind = rng.integers(0, 8, n)
+        d[kind == 0] = np.eye(3)[rng.integers(0, 3, (kind == 0).sum())] * rng.choice([-1.0, 1.0], ((kind == 0).sum(), 1))
+        z = kind == 1
+        d[z, rng.integers(0, 3, z.sum())] = rng.choice([0.0, -0.0], z.sum())
+        t = kind == 2
+        d[t, rng.integers(0, 3, t.sum())] = rng.choice([1e-38, -1e-38, 1e-42, -1e-30], t.sum())
+        rays = np.concatenate([o, d], 1).astype(np.float32)
+        monkeypatch.setenv("LRC_QNODES", "2")
+        q = lidarcast.Scene(engine.ctx, v, f)
+        monkeypatch.setenv("LRC_QNODES", "0")
+        w = lidarcast.Scene(engine.ctx, v, f)
+        monkeypatch.delenv("LRC_QNODES")
+        used += q.info["quantised_nodes"]
+        assert w.info["quantised_nodes"] == 0
+        a = q.cast(rays, want=("t", "prim", "point3"))
+        b = w.cast(rays, want=("t", "prim", "point3"))
+        assert_bit_equal(a["t"], b["t"])
+        assert np.array_equal(a["prim"], b["prim"])
+        assert_bit_equal(a["point3"], b["point3"])
+        if T <= 1500:                                      # and the definition itself on the smaller scenes
+            om = OracleMesh(v, f)
+            pick = rng.choice(n, 4000, replace=False)
+            t_bf, p_bf = om.brute(rays[pick])
+            assert_bit_equal(a["t"][pick], t_bf)
+            assert np.array_equal(a["prim"][pick], p_bf)
+        q.close(); w.close()
+    assert used >= 6          # most of these scenes take the grid (those offset by three widths do not)

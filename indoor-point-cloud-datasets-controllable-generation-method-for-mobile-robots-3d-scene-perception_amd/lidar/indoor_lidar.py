@@ -127,14 +127,24 @@ class DualAxisLidar:
         rnd = np.random if self.rng is None else self.rng
         if num_points is None:
             num_points = int(k.point_rate * k.scan_duration)
-        L = k.num_vertical_lines
-        per_line = num_points // L
-        base = np.linspace(k.theta_range[1], k.theta_range[0], L)
-        phi = np.linspace(0, 2 * np.pi, per_line, endpoint=False)
-        phase = np.arange(L) * np.pi / L
-        theta = base[:, None] + k.swing_amplitude * np.sin(k.swing_frequency * phi[None, :] + phase[:, None])
-        theta = np.clip(theta, k.theta_range[0], k.theta_range[1]).reshape(-1)
-        phi = np.broadcast_to(phi[None, :], (L, per_line)).reshape(-1).copy()
+        # the noise-free pattern depends on the intrinsics alone: computed once per intrinsics object and scan size
+        key = (num_points, k.num_vertical_lines, tuple(k.theta_range), k.swing_amplitude, k.swing_frequency)
+        cached = getattr(k, "_scan_pattern", None)
+        if cached is None or cached[0] != key:
+            L = k.num_vertical_lines
+            per_line = num_points // L
+            base = np.linspace(k.theta_range[1], k.theta_range[0], L)
+            phi = np.linspace(0, 2 * np.pi, per_line, endpoint=False)
+            phase = np.arange(L) * np.pi / L
+            theta = base[:, None] + k.swing_amplitude * np.sin(k.swing_frequency * phi[None, :] + phase[:, None])
+            theta = np.clip(theta, k.theta_range[0], k.theta_range[1]).reshape(-1)
+            phi = np.broadcast_to(phi[None, :], (L, per_line)).reshape(-1).copy()
+            cached = (key, phi, theta)
+            try:
+                k._scan_pattern = cached
+            except Exception:          # frozen / slotted intrinsics: no cache
+                pass
+        phi, theta = cached[1].copy(), cached[2].copy()
         n = phi.size
         if k.angle_noise_std > 0:
             z = rnd.normal(0, k.angle_noise_std, size=2 * n).reshape(n, 2)
@@ -150,6 +160,12 @@ class DualAxisLidar:
         buffer), and the dropout keep mask (N,) bool or None.  ``rays[keep]`` is ``get_multi_line_rays()``; consumes the
         RNG exactly as it does.  The batched engine path casts all rays with the mask instead of a ragged subset."""
         phi, theta, keep = self.scan_angles(num_points)
+        return self.rays_from_angles(phi, theta, out), keep
+
+    def rays_from_angles(self, phi, theta, out: np.ndarray = None):
+        """(N,6) float32 rays of the scan angles (phi, theta): the trigonometry, rotation and narrowing of the reference's
+        generator (lidar/indoor_lidar.py:274-291), no random draws -- callers that scan many poses draw the angles pose
+        after pose (the seeded stream is sequential by definition) and run this part on a thread pool."""
         ct = np.cos(theta)
         d = np.stack([ct * np.cos(phi), ct * np.sin(phi), np.sin(theta)], axis=-1)
         R = self.pose[:3, :3]
@@ -158,7 +174,7 @@ class DualAxisLidar:
         rays = np.empty((len(d), 6), dtype=np.float32) if out is None else out
         rays[:, :3] = self.pose[:3, 3].astype(np.float32)
         rays[:, 3:] = world.astype(np.float32)
-        return rays, keep
+        return rays
 
     def get_multi_line_rays(self, num_points: int = None) -> np.ndarray:
         rays, keep = self.all_rays_and_mask(num_points)

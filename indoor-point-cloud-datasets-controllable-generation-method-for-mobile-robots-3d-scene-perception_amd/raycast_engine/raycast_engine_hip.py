@@ -54,6 +54,19 @@ def _fingerprint(v, f, full=False):
     return (v.shape, f.shape, str(v.dtype), str(f.dtype), h.hexdigest())
 
 
+_RAY_POOL = None
+
+
+def _ray_pool():
+    """Threads for the host-side ray generation of the dual-axis sensor (pure numpy work per pose)."""
+    global _RAY_POOL
+    if _RAY_POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _RAY_POOL = ThreadPoolExecutor(max_workers=max(1, min(16, (os.cpu_count() or 2) - 1)))
+    return _RAY_POOL
+
+
 class RaycastEngineHIP(RaycastEngineBase):
     """HIP (gfx950) engine.  ``RaycastEngineGPU`` is this class."""
 
@@ -274,12 +287,22 @@ class RaycastEngineHIP(RaycastEngineBase):
         rays = self.ctx.pinned.take(P * n * 24)[:P * n * 24].view(np.float32).reshape(P, n, 6)
         keep = self.ctx.pinned.take(P * n)[:P * n].reshape(P, n)
         keep[:] = 1
+        # the random draws are sequential by definition of the seeded stream (pose after pose, angles then dropout);
+        # the trigonometry and rotation of a pose depend on nothing else and run on a thread pool beside the next
+        # poses' draws (numpy releases the GIL in both); at most 48 poses' angle arrays are alive
+        import collections
+        pool, pending = _ray_pool(), collections.deque()
         for i, l in enumerate(lidars):
-            r, k = l.all_rays_and_mask(out=rays[i])
-            if len(r) != n:
+            phi, theta, k = l.scan_angles()
+            if phi.size != n:
                 raise ValueError("dual-axis poses must share one ray count")
             if k is not None:
                 keep[i] = k
+            pending.append(pool.submit(l.rays_from_angles, phi, theta, rays[i]))
+            while len(pending) > 48:
+                pending.popleft().result()
+        for f in pending:
+            f.result()
         centers = np.stack([np.asarray(l.pose, dtype=np.float64)[:3, 3] for l in lidars])
         return self.scene_for(mesh).scan_rays_compact(rays, keep, centers, k0.max_range, want=want)
 

@@ -19,6 +19,9 @@ import os
 import sys
 import time
 
+# the pool's host driver supports dmabuf IPC only: without this RCCL's buffer registration across ranks fails
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(REPO, "indoor-point-cloud-datasets-controllable-generation-method-for-mobile-"
                          "robots-3d-scene-perception_amd")

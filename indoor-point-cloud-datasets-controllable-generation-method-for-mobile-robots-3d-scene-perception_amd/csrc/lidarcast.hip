@@ -607,6 +607,16 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
         auto fetch_step = [&]() {         // per-lane fetch of node `ref`
             if (QM == 2) {
                 const uint4* n = p.nodes_q4 + (size_t)ref * 4;
+#ifdef LRC_EXP_TIMING
+                if (STATS) {
+                    const uint64_t c0 = __builtin_amdgcn_s_memtime();
+                    const uint4 a = n[0], b = n[1], c = n[2], e = n[3];
+                    asm volatile("s_waitcnt vmcnt(0)" :: "v"(a.x), "v"(b.x), "v"(c.x), "v"(e.x));
+                    st_uni += (uint32_t)(__builtin_amdgcn_s_memtime() - c0);
+                    step_q4(a, b, c, e);
+                    return;
+                }
+#endif
                 step_q4(n[0], n[1], n[2], n[3]);
             } else if (Q) {
                 const uint4* n = p.nodes_q + (size_t)ref * 2;
@@ -681,6 +691,7 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
     };
 #ifdef LRC_EXP_TIMING
     const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+    const uint64_t r_begin = __builtin_amdgcn_s_memrealtime();      // 100 MHz
 #endif
     if (p.num_nodes) {
         if (QN) {
@@ -715,7 +726,7 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
     }
 
 #ifdef LRC_EXP_TIMING
-    if (STATS) { st_dead = (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin); st_pad = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live)); }
+    if (STATS) { st_dead = (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin); st_pad = (uint32_t)(__builtin_amdgcn_s_memrealtime() - r_begin); }
 #endif
     // ---- fused write-back ----
     if (GEN != 0) {

@@ -31,3 +31,5 @@ print(f"scene {name}: {st.shape[0]} waves in one launch")
 print(f"traversal clocks per wave: mean {w_total.mean():.0f}  p50 {np.median(w_total):.0f}  p90 {np.percentile(w_total, 90):.0f}")
 print(f"of which waiting for per-lane node fetches: mean {w_wait.mean():.0f} = {w_wait.mean() / w_total.mean():.0%}")
 print(f"per wave: max node steps over lanes {it_nodes.mean():.1f}, max triangle tests {it_tris.mean():.1f}")
+real = st[..., 4].max(1)                               # the same span in 100 MHz ticks (s_memrealtime)
+print(f"shader clock during the launch: {w_total.sum() / real.sum() * 0.1:.2f} GHz (s_memtime / s_memrealtime)")

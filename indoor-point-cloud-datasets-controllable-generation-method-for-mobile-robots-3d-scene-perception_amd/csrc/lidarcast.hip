@@ -11,6 +11,8 @@
 //                        scalar cache (s_load); fused hit write-back (t, prim, normal, point, labels, range
 //                        filter, incident angle, packed (t,label) pair, per-wave keep count).
 //                        GEN = rays generated from (pose, direction table) inside the kernel.
+//                        QN = per-lane node fetches from the 32-byte quantised node images (15-bit grid per axis,
+//                        one v_perm_b32 per plane); float32 world-space nodes for the rays the grid is not proven for.
 //   compact_*            stable stream compaction of the fixed-stride records into frame order.
 //   cloud_*              the same compaction with the hit point rebuilt from (t, label) pairs (multi-GPU assembly).
 #include <hip/hip_runtime.h>

@@ -1,6 +1,8 @@
 """AddressSanitizer + UndefinedBehaviorSanitizer over the host-side native code (the threaded SAH builder of the
 product and the C oracle), CPU build only; the same harness checks that the builder's output is byte-identical for
-1, 4 and 16 build threads and that the oracle's BVH equals its brute force."""
+1, 4 and 16 build threads, that the oracle's BVH equals its brute force, and the quantised node images
+(csrc/lrc_qnodes.cpp): containment with the margin, decode, the four-wide collapse reaching the same leaves, and -- with the
+kernel's box arithmetic restated -- that no box on the path to a brute-force hit fails the quantised test."""
 import os
 import shutil
 import subprocess
@@ -18,11 +20,12 @@ def test_builder_and_oracle_under_asan_ubsan(tmp_path):
     subprocess.run(["gcc", *flags, "-ffp-contract=off", "-c", os.path.join(REPO, "oracle", "lrc_oracle.c"), "-o", str(obj)],
                    check=True, capture_output=True, text=True)
     exe = tmp_path / "harness"
-    subprocess.run(["g++", "-std=c++17", *flags, "-I", csrc, os.path.join(REPO, "tests", "native", "sanitize_harness.cpp"),
-                    os.path.join(csrc, "bvh_build.cpp"), str(obj), "-o", str(exe), "-pthread", "-lm"],
+    subprocess.run(["g++", "-std=c++17", *flags, "-ffp-contract=off", "-I", csrc, os.path.join(REPO, "tests", "native", "sanitize_harness.cpp"),
+                    os.path.join(csrc, "bvh_build.cpp"), os.path.join(csrc, "lrc_qnodes.cpp"), str(obj), "-o", str(exe), "-pthread", "-lm"],
                    check=True, capture_output=True, text=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-3000:])
     assert r.stdout.count(" ok") == 6 and "MISMATCH" not in r.stdout and "NONDETERMINISTIC" not in r.stdout
+    assert "QNODES" not in r.stdout and r.stdout.count("hit rays checked along their paths") >= 3, r.stdout[-1500:]
     assert "runtime error" not in r.stderr

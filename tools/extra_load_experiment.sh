@@ -11,7 +11,7 @@ if [ "${1:-run}" = build ]; then
   mkdir -p $R/build_variants
   cd $PKG/csrc
   for x in 1 2 3; do
-    hipcc $FLAGS -DLRC_EXP_EXTRA_NODE_LOADS=$x lidarcast.hip lrc_nn.hip lrc_metrics.hip lrc_occupancy.hip bvh_build.cpp -o $R/build_variants/libx$x.so || exit 1
+    hipcc $FLAGS -DLRC_EXP_EXTRA_NODE_LOADS=$x lidarcast.hip lrc_nn.hip lrc_metrics.hip lrc_occupancy.hip bvh_build.cpp lrc_qnodes.cpp -o $R/build_variants/libx$x.so || exit 1
   done
   exit 0
 fi

@@ -701,7 +701,7 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
             // outside this bound the margin of the quantised boxes is not proven to cover the difference
             // between the two slab arithmetics: such a wave walks the float32 nodes
             auto far1 = [](float oa, float da, float base, float W) {
-                return !(__builtin_fabsf(oa - base) <= 6.f * W) | !(__builtin_fabsf(oa) <= 12.f * W) |
+                return !(__builtin_fabsf(oa - base) <= lrc::kQnodeNearBase * W) | !(__builtin_fabsf(oa) <= lrc::kQnodeNearOrigin * W) |
                        !(__builtin_fabsf(da) <= 0x1p60f);
             };
             const bool far = live & (far1(o.x, d.x, p.qbase[0], p.qW[0]) | far1(o.y, d.y, p.qbase[1], p.qW[1]) |

@@ -29,7 +29,7 @@ bool make_qgrid(const HostBVH& h, float base[3], float W[3], float invW[3], QGri
         float bf = (float)b;
         if ((double)bf > b) bf = std::nextafter(bf, -INFINITY);
         g.bd[a] = (double)bf;
-        if (!(std::fabs(g.bd[a]) <= 8.0 * g.Wd[a])) return false;    // a scene this far from the world origin: all rays "far"
+        if (!(std::fabs(g.bd[a]) <= kQnodeMaxBase * g.Wd[a])) return false;    // a scene this far from the world origin: all rays "far"
         base[a] = bf; W[a] = (float)g.Wd[a]; invW[a] = (float)(1.0 / g.Wd[a]);
     }
     return true;

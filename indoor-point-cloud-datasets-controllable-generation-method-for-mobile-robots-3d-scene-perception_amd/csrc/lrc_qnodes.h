@@ -10,6 +10,16 @@ namespace lrc {
 
 constexpr double kQnodeMaxInflation = 1.05;   // images are built while the mean growth of a leaf box stays below this
 constexpr double kQnodeMargin = 1.0 / 16;     // cells; see the bound in DESIGN.md section 4.1
+// The bound the margin is proven for, in units of W per axis: a ray takes the quantised path only if its origin o has
+// |o - base| <= kQnodeNearBase * W and |o| <= kQnodeNearOrigin * W (and |d| <= 2^60); the builder refuses a scene whose
+// base is farther than kQnodeMaxBase * W from the world origin (an origin inside such a scene would fail the second test).
+// 2^-24 (4 * 6 + 12 + 8) W = 2.7e-6 W < margin * cell = 2^-18 W.
+constexpr float kQnodeNearBase = 6.0f;
+constexpr float kQnodeNearOrigin = 12.0f;
+constexpr double kQnodeMaxBase = 8.0;
+static_assert((4.0 * kQnodeNearBase + kQnodeNearOrigin + 8.0) / 16777216.0 < kQnodeMargin / 16384.0,
+              "the margin must cover the arithmetic bound");
+static_assert(kQnodeMaxBase + 4.0 <= kQnodeNearOrigin, "origins inside the scene must pass the |o| test");
 
 struct QGrid { double Wd[3], bd[3]; };        // per axis: cell width * 2^14 (a power of two) and the float32 base
 

@@ -88,7 +88,7 @@ static int check_qnodes(const lrc::HostBVH& h, const float* rays, uint64_t N, co
         for (int a = 0; a < 3; ++a) {
             ixq[a] = safe_inv(r[3 + a]) * W[a];
             oxq[a] = ((r[a] - base[a]) * invW[a]) * ixq[a];
-            near = near && std::fabs(r[a] - base[a]) <= 6.f * W[a] && std::fabs(r[a]) <= 12.f * W[a] && std::fabs(r[3 + a]) <= 0x1p60f;
+            near = near && std::fabs(r[a] - base[a]) <= lrc::kQnodeNearBase * W[a] && std::fabs(r[a]) <= lrc::kQnodeNearOrigin * W[a] && std::fabs(r[3 + a]) <= 0x1p60f;
         }
         if (!near) continue;                      // the kernel walks the float32 nodes for this ray
         const int32_t slot = slot_of_prim[p_bf[i]];
@@ -135,6 +135,21 @@ int main() {
             orc_cast_brute(v.data(), f.data(), T, rays.data(), N, t1.data(), p1.data());
             for (uint64_t i = 0; i < N; ++i) if (p1[i] != p2[i]) { printf("MISMATCH round %d ray %lu\n", round, (unsigned long)i); return 1; }
             if (int rc = check_qnodes(h, rays.data(), N, t1.data(), p1.data(), round)) return rc;
+            if (T <= 1000) {     // and out to the edge of the bound the margin is proven for: origins up to ~6 W from the base
+                std::vector<float> far(N * 6), tf(N); std::vector<uint32_t> pf(N);
+                float ext = 0.f;
+                for (int a = 0; a < 3; ++a) ext = std::fmax(ext, h.bounds_hi[a] - h.bounds_lo[a]);
+                for (uint64_t i = 0; i < N; ++i) {
+                    const uint64_t tri = (uint64_t)(rnd() * 0.999f * T);
+                    float c[3], u[3], len = 0.f;
+                    for (int a = 0; a < 3; ++a) { c[a] = (v[tri * 9 + a] + v[tri * 9 + 3 + a] + v[tri * 9 + 6 + a]) / 3.f; u[a] = rnd() - 0.5f; len += u[a] * u[a]; }
+                    len = std::sqrt(len) + 1e-9f;
+                    const float dist = rnd() * 6.f * ext;
+                    for (int a = 0; a < 3; ++a) { far[i * 6 + 3 + a] = u[a] / len; far[i * 6 + a] = c[a] - u[a] / len * dist; }
+                }
+                orc_cast_brute(v.data(), f.data(), T, far.data(), N, tf.data(), pf.data());
+                if (int rc = check_qnodes(h, far.data(), N, tf.data(), pf.data(), round)) return rc;
+            }
         }
         {   // the diagnostic cast returns the same hits; the float64 witness and its one-triangle form run clean,
             // also on rays with non-finite components (finite-ray contract: a miss)

@@ -161,6 +161,7 @@ struct TraceParams {
     const uint4* nodes_q4;     // QN = 2: the tree collapsed to four children per node, 64 B per node ...
     const float4* nodes_n4;    // ... and 128 B per node as normalised float32
     uint32_t stack_cap;        // entries of the per-lane LDS stack
+    uint32_t force_redo;       // test hook (LRC_DEBUG_FORCE_REDO=m): rays with gid % m == 0 take the redo path as well
     float qbase[3], qW[3], qinvW[3];   // normalised coordinate n = (x - qbase) * qinvW in [2, 4); qW = 1 / qinvW = 2^k
     // inputs
     const float* rays6;        // explicit rays (GEN = false)
@@ -426,7 +427,8 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
     // conservative with respect to the hit definition (lrc_device.h), the closest hit is order independent.
     // qtag 0: float32 world-space nodes.  1: quantised images; all rays of the wave point into one direction octant, so
     // the plane selectors are wave-uniform and live in SGPRs.  2: the same on the four-wide collapse of the tree.
-    bool ovf = false;          // qtag 2: this lane's stack would not have held a step's pushes; the ray is redone on qtag 0
+    bool redo = false;         // quantised paths: this ray must be redone on qtag 0 (its closest candidate failed the box
+                               // clause, or -- qtag 2 -- its stack would not have held a step's pushes)
     auto traverse = [&](auto qtag) {
         constexpr int QM = decltype(qtag)::value;
         constexpr bool Q = QM != 0;
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
             const float dm = min2(min2(d0, d1), min2(d2, d3));
             if (dm < inf) {
                 if (sp + 3 > (int)p.stack_cap) {      // cannot happen on a tree whose depth the stack was sized for
-                    ovf = true; ref = ~0; sp = 0;     // ... unless three children stay pending level after level
+                    redo = true; ref = ~0; sp = 0;    // ... unless three children stay pending level after level
                 } else {
                     const int near = d0 == dm ? 0 : d1 == dm ? 1 : d2 == dm ? 2 : 3;
                     if (h3 & (near != 3)) { s_stack[sp * kTBlock + tid] = r3; ++sp; }
@@ -578,19 +580,12 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
                         float t;
                         bool hit;
                         if (Q) {
-                            // the definition's box clause is in world coordinates: its slab constants are rebuilt from
-                            // the normalised ones (ix = ix' / W exactly; ox = o * ix as make_slab forms it) for the
-                            // few triangles that pass the Moeller-Trumbore conditions
-                            hit = tri_hit_with<STATS>(o, d, [&] {
-                                RaySlab w;
-                                float k0 = p.qinvW[0], k1 = p.qinvW[1], k2 = p.qinvW[2];
-                                // opaque to the optimiser: otherwise the six constants are hoisted out of the loop and
-                                // held in registers for its whole duration (8 waves per SIMD need <= 64 VGPRs)
-                                asm volatile("" : "+s"(k0), "+s"(k1), "+s"(k2));
-                                w.ix = sl.ix * k0; w.iy = sl.iy * k1; w.iz = sl.iz * k2;
-                                w.ox = o.x * w.ix; w.oy = o.y * w.iy; w.oz = o.z * w.iz;
-                                return w;
-                            }, v0, v1, v2, ng, t, &st_pad);
+                            // Candidates are ranked by the Moeller-Trumbore conditions alone; the definition's box
+                            // clause (world coordinates) is tested once, after the traversal, on the closest candidate.
+                            // If that candidate passes, it is the definition's closest hit: every triangle passing both
+                            // tests is a candidate too, and pruning by a candidate's t never hides a closer one.  If it
+                            // fails -- never observed -- the ray is redone on the float32 nodes with the clause inline.
+                            hit = tri_mt(o, d, v0, v1, v2, ng, t);
                         } else {
                             hit = tri_hit<STATS>(o, d, sl, v0, v1, v2, ng, t, &st_pad);
                         }
@@ -691,6 +686,21 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
             --sp;
             ref = s_stack[sp * kTBlock + tid];
         }
+        if (Q) {
+            if (best_slot != 0xFFFFFFFFu) {       // the box clause of the closest candidate, in world coordinates
+                const float4* tr = p.tris + (size_t)best_slot * 3;
+                const float4 a = tr[0], b = tr[1], c = tr[2];
+                const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x};
+                RaySlab w;      // ix = ix' / W exactly (W a power of two); ox = o * ix as make_slab forms it
+                w.ix = sl.ix * p.qinvW[0]; w.iy = sl.iy * p.qinvW[1]; w.iz = sl.iz * p.qinvW[2];
+                w.ox = o.x * w.ix; w.oy = o.y * w.iy; w.oz = o.z * w.iz;
+                if (!tri_clause(w, v0, v1, v2, tbest)) {
+                    redo = true;
+                    if (STATS) st_pad += 1u;
+                }
+            }
+            if (p.force_redo) redo |= (gid % p.force_redo) == 0;
+        }
     };
 #ifdef LRC_EXP_TIMING
     const uint64_t t_begin = __builtin_amdgcn_s_memtime();
@@ -711,16 +721,13 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
             // a wave whose rays point into different octants (it straddles an axis direction) walks the float32 nodes too
             if (__builtin_amdgcn_ballot_w64(far | (live & (oct != oct0))) != 0ull) { if (live) traverse(IntTag<0>{}); }
             else if (live) {
-                if (QN == 2) {
-                    traverse(IntTag<2>{});
-                    if (__builtin_amdgcn_ballot_w64(ovf) != 0ull) {
-                        if (ovf) {
-                            tbest = __builtin_inff(); best_slot = 0xFFFFFFFFu; best_prim = 0xFFFFFFFFu;
-                            traverse(IntTag<0>{});
-                        }
-                    }
-                } else {
-                    traverse(IntTag<1>{});
+                if (QN == 2) traverse(IntTag<2>{});
+                else traverse(IntTag<1>{});
+            }
+            if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+                if (redo) {
+                    tbest = __builtin_inff(); best_slot = 0xFFFFFFFFu; best_prim = 0xFFFFFFFFu;
+                    traverse(IntTag<0>{});
                 }
             }
         } else if (live) {
@@ -1394,6 +1401,7 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
     const uint32_t depth = s->info.max_depth < 1 ? 1 : s->info.max_depth;
     const size_t lds = (size_t)depth * kTBlock * sizeof(int);
     p.stack_cap = depth;
+    if (const char* e = std::getenv("LRC_DEBUG_FORCE_REDO")) p.force_redo = (uint32_t)std::atoi(e);
     // measured alternative: the four-wide collapse; built and walked only under LRC_WIDE=1
     const int wide = s->d_nodes_q4 != nullptr;
     static const int leafw = [] { const char* e = std::getenv("LRC_LEAFW"); return e ? std::atoi(e) : 1; }();

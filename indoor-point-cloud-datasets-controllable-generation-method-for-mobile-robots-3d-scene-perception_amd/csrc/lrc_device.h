@@ -111,10 +111,10 @@ LRC_DI bool tri_hit(V3 o, V3 d, const RaySlab& s, V3 v0, V3 v1, V3 v2, V3 ng, fl
     return true;
 }
 
-// tri_hit with the ray's slab constants produced on demand (slab() is called only for a triangle that passes the
-// Moeller-Trumbore conditions, which is when the box clause needs them): identical conditions and arithmetic.
-template <bool DIAG = false, class SlabFn>
-LRC_DI bool tri_hit_with(V3 o, V3 d, SlabFn slab, V3 v0, V3 v1, V3 v2, V3 ng, float& t_out, uint32_t* pad_rej = nullptr) {
+// The two halves of tri_hit, for callers that test the box clause once, for the closest candidate only (trace_kernel on the
+// quantised nodes): tri_mt = the Moeller-Trumbore conditions and t (finite), tri_clause = the padded box interval of the
+// triangle.  tri_mt && tri_clause is tri_hit, expression for expression.
+LRC_DI bool tri_mt(V3 o, V3 d, V3 v0, V3 v1, V3 v2, V3 ng, float& t_out) {
     V3 e1 = sub3(v0, v1);
     V3 e2 = sub3(v2, v0);
     V3 c = sub3(v0, o);
@@ -128,18 +128,17 @@ LRC_DI bool tri_hit_with(V3 o, V3 d, SlabFn slab, V3 v0, V3 v1, V3 v2, V3 ng, fl
     bool ok = (den != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= aden) & (tt > 0.0f);
     if (!ok) return false;
     float t = tt / aden;
-    const RaySlab s = slab();
+    if (!(t < __builtin_inff())) return false;
+    t_out = t;
+    return true;
+}
+LRC_DI bool tri_clause(const RaySlab& s, V3 v0, V3 v1, V3 v2, float t) {
     float lox = min2(min2(v0.x, v1.x), v2.x), hix = max2(max2(v0.x, v1.x), v2.x);
     float loy = min2(min2(v0.y, v1.y), v2.y), hiy = max2(max2(v0.y, v1.y), v2.y);
     float loz = min2(min2(v0.z, v1.z), v2.z), hiz = max2(max2(v0.z, v1.z), v2.z);
     float tn, tf;
     slab_interval(s, lox, loy, loz, hix, hiy, hiz, tn, tf);
-    if (!((tn <= t) & (t <= tf) & (t < __builtin_inff()))) {
-        if (DIAG) { if (t < __builtin_inff()) *pad_rej += 1u; }
-        return false;
-    }
-    t_out = t;
-    return true;
+    return (tn <= t) & (t <= tf);
 }
 
 // tri_hit for callers that have no RaySlab at hand (sector_kernel tests a few rays against one triangle): identical

@@ -957,8 +957,9 @@ def test_export_labels_from_annotated_cloud(tmp_path, engine):
 
 def test_kernel_variants_are_bit_identical():
     """Traversal order / fetch strategy / leaf size must not change a single output byte:
-    the scalar-fetch, leaf-pair, speculative-postponement, small-leaf and node-image (float32 / quantised) variants
-    against the default."""
+    the scalar-fetch, leaf-pair, speculative-postponement, small-leaf and node-image (float32 / quantised / four-wide)
+    variants against the default, and the quantised path with every third / every ray sent through its redo path (the
+    route a ray takes when its closest candidate fails the box clause, which no input so far has made happen)."""
     import subprocess
     import sys
     from conftest import REPO
@@ -970,7 +971,9 @@ def test_kernel_variants_are_bit_identical():
                       "refill_4": {"LRC_REFILL": "4"}, "refill_2_w7": {"LRC_REFILL": "2", "LRC_REFILL_W": "7"},
                       "float32_nodes": {"LRC_QNODES": "0"}, "quantised_nodes_forced": {"LRC_QNODES": "2"},
                       "quantised_leaf_pairs": {"LRC_QNODES": "2", "LRC_LEAFW": "2"},
-                      "four_wide_nodes": {"LRC_QNODES": "2", "LRC_WIDE": "1"}}.items():
+                      "four_wide_nodes": {"LRC_QNODES": "2", "LRC_WIDE": "1"},
+                      "every_third_ray_redone": {"LRC_QNODES": "2", "LRC_DEBUG_FORCE_REDO": "3"},
+                      "every_ray_redone": {"LRC_QNODES": "2", "LRC_DEBUG_FORCE_REDO": "1"}}.items():
         e = dict(os.environ)
         e.update(env)
         r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=300, env=e, check=True)

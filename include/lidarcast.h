@@ -88,6 +88,9 @@ typedef struct lrc_scene_info {
     float    bounds_hi[3];
     uint32_t quantised_nodes;  /* 1: the trace kernels walk the 32-byte quantised node images of this tree   */
     float    leaf_inflation;   /* mean half perimeter of a leaf box on the 15-bit grid / of its float32 box  */
+    uint32_t device_build;     /* 1: the BVH was built on the GPU (build_ms = hierarchy + layout kernels,
+                                  upload_ms = mesh transfer + validation); 0: host builder                     */
+    uint32_t reserved_;
 } lrc_scene_info;
 
 #define LRC_MAX_BVH_DEPTH 32
@@ -107,8 +110,12 @@ int lrc_ctx_create(int device, lrc_ctx** out_ctx);
 int lrc_ctx_destroy(lrc_ctx* ctx);
 int lrc_ctx_synchronize(lrc_ctx* ctx);
 
-/* Build the scene once per mesh: narrow-free copy of float32 vertices (V,3) and uint32 triangle
- * rows (T,3), host SAH BVH build, upload.  tri_sem / tri_ins are optional per-triangle labels.
+/* Build the scene once per mesh: float32 vertices (V,3) and uint32 triangle rows (T,3) in, binned-SAH
+ * BVH (leaves <= 4 triangles, bounded depth), triangle records, id / label / plane tables and the
+ * quantised node images out, all resident in HBM.  tri_sem / tri_ins are optional per-triangle labels.
+ * The build runs ON THE GPU (csrc/lrc_bvh_device.hip; milliseconds for a 10^6-triangle mesh); the
+ * host builder (csrc/bvh_build.cpp) produces the same tree and the same bytes and serves meshes of a
+ * handful of triangles and LRC_DEVICE_BUILD=0.
  * Replaces RaycastingScene() + TriangleMesh.from_legacy + add_triangles, which the reference
  * repeats on every call (raycast_engine_cpu.py:46-47, raycast_engine.py:20-24).
  * T == 0 is allowed (every ray misses). */
@@ -117,6 +124,13 @@ int lrc_scene_create(lrc_ctx* ctx,
                      const uint32_t* tris3, uint64_t num_triangles,
                      const uint16_t* tri_sem, const uint16_t* tri_ins,
                      lrc_scene** out_scene);
+/* The same for a mesh that is already in HBM (DEVICE pointers; labels may be NULL): nothing crosses
+ * PCIe.  Synchronous like lrc_scene_create; the input arrays may be released on return. */
+int lrc_scene_create_dev(lrc_ctx* ctx,
+                         const float* d_verts3, uint64_t num_vertices,
+                         const uint32_t* d_tris3, uint64_t num_triangles,
+                         const uint16_t* d_tri_sem, const uint16_t* d_tri_ins,
+                         lrc_scene** out_scene);
 int lrc_scene_destroy(lrc_scene* scene);
 int lrc_scene_get_info(const lrc_scene* scene, lrc_scene_info* out_info);
 
@@ -125,6 +139,17 @@ int lrc_scene_get_info(const lrc_scene* scene, lrc_scene_info* out_info);
  *             int32 bit patterns: >=0 inner node index, <0 leaf: ~ref = first_slot*8 + count)
  *   slot_prim: num_slots uint32 (triangle row index stored in each leaf slot) */
 int lrc_scene_export_bvh(const lrc_scene* scene, float* nodes16, uint32_t* slot_prim);
+
+/* Copy one of the scene's device arrays back (tests compare the device builder's bytes with the host builder's).
+ * dst may be NULL to ask for the size only (*out_bytes; 0 for an array this scene does not have). */
+#define LRC_ARRAY_NODES       0   /* num_nodes x 64 B                                      */
+#define LRC_ARRAY_TRIS        1   /* num_slots x 48 B: v0 v1 v2 Ng                         */
+#define LRC_ARRAY_SLOT_PRIM   2   /* num_slots x u32                                       */
+#define LRC_ARRAY_SLOT_LABEL  3   /* num_slots x u32: sem | ins << 16                      */
+#define LRC_ARRAY_PRIM_PLANE  4   /* num_triangles x 32 B: (v0, label bits), (Ng, 0)       */
+#define LRC_ARRAY_NODES_Q     5   /* num_nodes x 32 B quantised image                      */
+#define LRC_ARRAY_NODES_N     6   /* num_nodes x 64 B normalised float32 image             */
+int lrc_scene_export_array(const lrc_scene* scene, int which, void* dst, uint64_t dst_bytes, uint64_t* out_bytes);
 
 /* ---- cast: explicit rays --------------------------------------------------------------------
  * rays6 is (N,6) float32 rows [ox,oy,oz,dx,dy,dz] (raycast_engine_cpu.py:24-38).

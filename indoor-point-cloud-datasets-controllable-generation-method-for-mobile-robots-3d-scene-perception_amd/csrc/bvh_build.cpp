@@ -31,16 +31,23 @@ struct Prim {
     uint32_t id;
 };
 
+// min / max under the total order of the float32 bit patterns (-0.0 < +0.0): a box plane does not depend on the
+// order its members were visited in, so the device builder (lrc_bvh_device.hip, integer min / max on the same
+// encoding) produces the same bytes.  The sign of a zero plane never changes a traversal result.
+inline int32_t ford(float f) { int32_t i; std::memcpy(&i, &f, 4); return i ^ ((i >> 31) & 0x7FFFFFFF); }
+inline float fmin_t(float a, float b) { return ford(b) < ford(a) ? b : a; }
+inline float fmax_t(float a, float b) { return ford(b) > ford(a) ? b : a; }
+
 struct Box {
     float lo[3], hi[3];
     void reset() {
         for (int k = 0; k < 3; ++k) { lo[k] = FLT_MAX; hi[k] = -FLT_MAX; }
     }
     void grow(const float* l, const float* h) {
-        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], l[k]); hi[k] = std::max(hi[k], h[k]); }
+        for (int k = 0; k < 3; ++k) { lo[k] = fmin_t(lo[k], l[k]); hi[k] = fmax_t(hi[k], h[k]); }
     }
     void grow_pt(const float* p) {
-        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
+        for (int k = 0; k < 3; ++k) { lo[k] = fmin_t(lo[k], p[k]); hi[k] = fmax_t(hi[k], p[k]); }
     }
     double half_area() const {
         double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
@@ -75,6 +82,7 @@ struct Builder {
     std::vector<TmpNode> nodes;              // pool, sized up front
     std::atomic<int64_t> next_node{0};
     int max_leaf = kMaxLeaf;
+    bool median_only = false;
     int fork_depth = 0;                      // fork while depth < fork_depth
     int depth_cap = kMaxDepth - 1;           // deepest allowed leaf (<= kMaxDepth - 1)
     std::atomic<uint32_t> max_depth{0};
@@ -96,6 +104,8 @@ struct Builder {
 
     int64_t make_leaf(uint64_t begin, uint64_t end, int depth) {
         uint64_t cnt = end - begin;
+        // slots of a leaf in triangle-row order: the layout is then a function of the tree alone
+        std::sort(prims.begin() + begin, prims.begin() + end, [](const Prim& a, const Prim& b) { return a.id < b.id; });
         atomic_max(max_depth, (uint32_t)depth);
         atomic_max(max_leaf_seen, (uint32_t)cnt);
         num_leaves.fetch_add(1, std::memory_order_relaxed);
@@ -122,7 +132,7 @@ struct Builder {
         // ---- binned SAH over the three axes ----
         double best_cost = DBL_MAX;
         int best_axis = -1, best_bin = -1;
-        for (int ax = 0; ax < 3; ++ax) {
+        for (int ax = 0; ax < 3 && !median_only; ++ax) {
             const float ext = cb.hi[ax] - cb.lo[ax];
             if (!(ext > 0.0f)) continue;
             const float scale = (float)kBins / ext;
@@ -213,6 +223,7 @@ void build_bvh(const float* verts3, uint64_t V, const uint32_t* tris3, uint64_t 
 
     Builder b;
     b.max_leaf = std::min(std::max(opt.max_leaf, 1), kMaxLeaf);
+    b.median_only = opt.median_only != 0;
     b.prims.resize(T);
     Box all; all.reset();
     for (uint64_t t = 0; t < T; ++t) {

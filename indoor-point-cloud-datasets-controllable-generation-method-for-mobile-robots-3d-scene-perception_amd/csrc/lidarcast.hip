@@ -27,6 +27,7 @@
 
 #include "../../include/lidarcast.h"
 #include "lrc_bvh.h"
+#include "lrc_bvh_device.h"
 #include "lrc_qnodes.h"
 #include "lrc_device.h"
 
@@ -95,6 +96,7 @@ struct lrc_ctx {
     hipEvent_t ev_chunk[8] = {}, ev_compact[8] = {};
     uint64_t* h_counts = nullptr;       // page-locked landing area of the per-pose counts and statistics (async copies
     uint64_t h_counts_cap = 0;          // need one): counts (P u64) | 4 x P doubles of per-pose statistics
+    lrc::DeviceArena build_arena;       // scratch of the device scene build, reused from scene to scene
 };
 
 struct lrc_table {            // a sensor's direction table resident in HBM (lrc_table_create)
@@ -105,6 +107,7 @@ struct lrc_table {            // a sensor's direction table resident in HBM (lrc
 
 struct lrc_scene {
     lrc_ctx* ctx = nullptr;
+    void* slab = nullptr;             // device-built scenes: ONE allocation holds every array below except d_slot_sphere / *4
     float4* d_nodes = nullptr;
     float4* d_tris = nullptr;
     uint32_t* d_slot_prim = nullptr;
@@ -1123,6 +1126,32 @@ __global__ __launch_bounds__(kBlock) void prim_scatter_kernel(const RebuildParam
     rebuild_tiles<R>(q, tile0, q.ntiles, threadIdx.x & 63u);
 }
 
+// Bounding sphere of every triangle's axis-aligned box (centre and half diagonal, rounded up): what sector_kernel
+// tests against a packet of rays before it runs the exact ray/triangle test.  Built on first use of the packet kernel.
+__global__ __launch_bounds__(kBlock) void slot_sphere_kernel(const float4* __restrict__ tris, uint32_t num_slots,
+                                                             float4* __restrict__ sphere) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= num_slots) return;
+    const float4 a = tris[(size_t)k * 3], b = tris[(size_t)k * 3 + 1], c = tris[(size_t)k * 3 + 2];
+    const float v[3][3] = {{a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}};
+    float ctr[3];
+    double lo[3], hi[3], hd2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        lo[q] = fmin(fmin((double)v[0][q], (double)v[1][q]), (double)v[2][q]);
+        hi[q] = fmax(fmax((double)v[0][q], (double)v[1][q]), (double)v[2][q]);
+        ctr[q] = (float)(0.5 * (lo[q] + hi[q]));
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {       // distance from the ROUNDED centre to the farthest corner
+        const double cc = (double)ctr[q];
+        const double e = fmax(hi[q] - cc, cc - lo[q]);
+        hd2 += e * e;
+    }
+    const float r = (float)__builtin_sqrt(hd2);
+    sphere[k] = make_float4(ctr[0], ctr[1], ctr[2], __uint_as_float(__float_as_uint(r) + 1u));    // nextafter(r, +inf), r >= 0
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1165,6 +1194,7 @@ int lrc_ctx_destroy(lrc_ctx* ctx) {
     for (int k = 0; k < kPoolSlots; ++k)
         if (ctx->pool[k]) (void)hipFree(ctx->pool[k]);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    lrc::arena_release(&ctx->build_arena);
     if (ctx->s_compute) (void)hipStreamDestroy(ctx->s_compute);
     if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
     if (ctx->s_stats) (void)hipStreamDestroy(ctx->s_stats);
@@ -1191,29 +1221,95 @@ int lrc_ctx_synchronize(lrc_ctx* ctx) {
 int lrc_scene_destroy(lrc_scene* s) {
     if (!s) return LRC_OK;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
-    if (s->d_nodes) (void)hipFree(s->d_nodes);
-    if (s->d_tris) (void)hipFree(s->d_tris);
-    if (s->d_slot_prim) (void)hipFree(s->d_slot_prim);
-    if (s->d_slot_label) (void)hipFree(s->d_slot_label);
-    if (s->d_prim_plane) (void)hipFree(s->d_prim_plane);
+    if (s->slab) {
+        (void)hipFree(s->slab);
+    } else {
+        if (s->d_nodes) (void)hipFree(s->d_nodes);
+        if (s->d_tris) (void)hipFree(s->d_tris);
+        if (s->d_slot_prim) (void)hipFree(s->d_slot_prim);
+        if (s->d_slot_label) (void)hipFree(s->d_slot_label);
+        if (s->d_prim_plane) (void)hipFree(s->d_prim_plane);
+        if (s->d_nodes_q) (void)hipFree(s->d_nodes_q);
+        if (s->d_nodes_n) (void)hipFree(s->d_nodes_n);
+    }
     if (s->d_slot_sphere) (void)hipFree(s->d_slot_sphere);
-    if (s->d_nodes_q) (void)hipFree(s->d_nodes_q);
-    if (s->d_nodes_n) (void)hipFree(s->d_nodes_n);
     if (s->d_nodes_q4) (void)hipFree(s->d_nodes_q4);
     if (s->d_nodes_n4) (void)hipFree(s->d_nodes_n4);
     delete s;
     return LRC_OK;
 }
 
-int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32_t* tris3, uint64_t T,
-                     const uint16_t* tri_sem, const uint16_t* tri_ins, lrc_scene** out_scene) {
-    if (!out_scene) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: out_scene is NULL");
-    *out_scene = nullptr;
-    if (!ctx) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: ctx is NULL");
-    if ((V && !verts3) || (T && !tris3))
-        return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: NULL vertex or triangle array");
-    if (T >= (1ull << 28) || V >= (1ull << 32))
-        return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: mesh too large (T < 2^28, V < 2^32)");
+namespace {
+
+int env_int(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
+
+lrc::BuildOptions build_options_from_env() {
+    lrc::BuildOptions opt;
+    opt.max_leaf = env_int("LRC_MAX_LEAF", opt.max_leaf);
+    opt.bfs_nodes = env_int("LRC_BFS_NODES", opt.bfs_nodes);
+    opt.depth_slack = env_int("LRC_DEPTH_SLACK", opt.depth_slack);
+    opt.median_only = env_int("LRC_BUILD_MEDIAN_ONLY", 0);      // test hook: every split takes the median fallback
+    return opt;
+}
+
+// LRC_QNODES: 0 = float32 nodes only, 1 (default) = quantised images when the grid is fine enough for the scene's
+// triangles, 2 = whenever the grid fits.  The grid has 2^15 cells along each axis of the scene; where the cells are
+// not small against the leaf boxes (a very large scene of small triangles) the widened boxes cost more triangle tests
+// than the smaller nodes save (measured: DESIGN.md section 4.1).
+int qnodes_mode() { static const int m = env_int("LRC_QNODES", 1); return m; }
+
+void qnodes_report(const lrc_scene* s, double infl) {
+    if (std::getenv("LRC_QNODES_VERBOSE"))
+        std::fprintf(stderr, "[qnodes] leaf box inflation %.3f, W = %g %g %g -> %s\n", infl, (double)s->qW[0],
+                     (double)s->qW[1], (double)s->qW[2], s->d_nodes_q ? "quantised images" : "float32 nodes");
+}
+
+// The scene build on the device (lrc_bvh_device.hip): the same tree, the same bytes as the host builder below, in
+// milliseconds.  Returns lrc::kDevBuildUnsupported (1) for a mesh the device path does not take (<= max_leaf triangles).
+int scene_create_device(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32_t* tris3, uint64_t T,
+                        const uint16_t* tri_sem, const uint16_t* tri_ins, bool on_device, lrc_scene** out_scene) {
+    lrc_scene* s = new (std::nothrow) lrc_scene();
+    if (!s) return fail(LRC_ERR_OOM, "lrc_scene_create: out of host memory");
+    s->ctx = ctx;
+    lrc::DeviceScene d;
+    std::string err;
+    const int rc = lrc::build_bvh_device(&ctx->build_arena, verts3, V, tris3, T, tri_sem, tri_ins, on_device,
+                                         build_options_from_env(), qnodes_mode(), &d, &err);
+    if (rc != lrc::kDevBuildOk) {
+        delete s;
+        return rc < 0 ? fail(rc, err) : rc;
+    }
+    s->slab = d.slab;
+    s->d_nodes = (float4*)d.nodes;
+    s->d_tris = (float4*)d.tris;
+    s->d_slot_prim = d.slot_prim;
+    s->d_slot_label = d.slot_label;
+    s->d_prim_plane = (float4*)d.prim_plane;
+    s->d_nodes_q = (uint4*)d.nodes_q;
+    s->d_nodes_n = (float4*)d.nodes_n;
+    for (int a = 0; a < 3; ++a) { s->qbase[a] = d.qbase[a]; s->qW[a] = d.qW[a]; s->qinvW[a] = d.qinvW[a]; }
+    lrc_scene_info& in = s->info;
+    in.num_vertices = V;
+    in.num_triangles = T;
+    in.num_nodes = d.num_nodes;
+    in.num_leaves = d.num_leaves;
+    in.num_slots = d.num_slots;
+    in.max_depth = d.max_depth;
+    in.max_leaf_size = d.max_leaf_size;
+    for (int k = 0; k < 3; ++k) { in.bounds_lo[k] = d.bounds_lo[k]; in.bounds_hi[k] = d.bounds_hi[k]; }
+    in.device_bytes = d.slab_bytes;
+    in.build_ms = d.ms_hierarchy + d.ms_emit;
+    in.upload_ms = d.ms_upload;
+    in.quantised_nodes = s->d_nodes_q ? 1u : 0u;
+    in.leaf_inflation = (float)d.leaf_inflation;
+    in.device_build = 1u;
+    qnodes_report(s, d.leaf_inflation);
+    *out_scene = s;
+    return LRC_OK;
+}
+
+int scene_create_host(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32_t* tris3, uint64_t T,
+                      const uint16_t* tri_sem, const uint16_t* tri_ins, lrc_scene** out_scene) {
     for (uint64_t i = 0; i < 3 * T; ++i)
         if (tris3[i] >= V)
             return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: triangle index out of range");
@@ -1224,17 +1320,12 @@ int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32
             return fail(LRC_ERR_INVALID_ARG,
                         "lrc_scene_create: vertex coordinate is not finite or exceeds 1e6");
     }
-    LRC_HIP(hipSetDevice(ctx->device));
-
     lrc_scene* s = new (std::nothrow) lrc_scene();
     if (!s) return fail(LRC_ERR_OOM, "lrc_scene_create: out of host memory");
     s->ctx = ctx;
 
     lrc::HostBVH h;
-    lrc::BuildOptions opt;
-    if (const char* e = std::getenv("LRC_MAX_LEAF")) opt.max_leaf = std::atoi(e);
-    if (const char* e = std::getenv("LRC_BFS_NODES")) opt.bfs_nodes = std::atoi(e);
-    if (const char* e = std::getenv("LRC_DEPTH_SLACK")) opt.depth_slack = std::atoi(e);
+    const lrc::BuildOptions opt = build_options_from_env();
     auto t0 = std::chrono::steady_clock::now();
     try {
         lrc::build_bvh(verts3, V, tris3, T, tri_sem, tri_ins, opt, &h);
@@ -1274,28 +1365,8 @@ int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32
         std::memcpy(&q[3], &h.slot_label[k], 4);
         q[4] = r[9]; q[5] = r[10]; q[6] = r[11];
     }
-    // bounding sphere of every triangle's axis-aligned box (centre and half diagonal, rounded up): what
-    // sector_kernel tests against a packet of rays before it runs the exact ray/triangle test
-    std::vector<float> sphere(h.slot_prim.size() * 4, 0.0f);
-    for (size_t k = 0; k < h.slot_prim.size(); ++k) {
-        const float* r = h.tri_rec.data() + k * 12;
-        double c[3], hd2 = 0.0;
-        for (int a = 0; a < 3; ++a) {
-            const double lo = std::min(std::min(r[a], r[3 + a]), r[6 + a]), hi = std::max(std::max(r[a], r[3 + a]), r[6 + a]);
-            c[a] = 0.5 * (lo + hi);
-            sphere[k * 4 + a] = (float)c[a];
-        }
-        for (int a = 0; a < 3; ++a) {       // distance from the ROUNDED centre to the farthest corner
-            const double lo = std::min(std::min(r[a], r[3 + a]), r[6 + a]), hi = std::max(std::max(r[a], r[3 + a]), r[6 + a]);
-            const double cc = (double)sphere[k * 4 + a];
-            const double e = std::max(hi - cc, cc - lo);
-            hd2 += e * e;
-        }
-        sphere[k * 4 + 3] = std::nextafter((float)std::sqrt(hd2), INFINITY);
-    }
     int rc;
-    if ((rc = upload((void**)&s->d_slot_sphere, sphere.data(), sphere.size() * 4)) ||
-        (rc = upload((void**)&s->d_prim_plane, prim_plane.data(), prim_plane.size() * 4)) ||
+    if ((rc = upload((void**)&s->d_prim_plane, prim_plane.data(), prim_plane.size() * 4)) ||
         (rc = upload((void**)&s->d_nodes, h.nodes.data(), h.nodes.size() * 4)) ||
         (rc = upload((void**)&s->d_tris, h.tri_rec.data(), h.tri_rec.size() * 4)) ||
         (rc = upload((void**)&s->d_slot_prim, h.slot_prim.data(), h.slot_prim.size() * 4)) ||
@@ -1306,20 +1377,16 @@ int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32
         return rc;
     }
     {
-        static const auto qn_env = [] { const char* e = std::getenv("LRC_QNODES"); return e ? std::atoi(e) : 1; };
         std::vector<uint32_t> q8, q16;
         std::vector<float> n16, n32;
-        // LRC_QNODES: 0 = float32 nodes only, 1 (default) = quantised images when the grid is fine enough for the
-        // scene's triangles, 2 = whenever the grid fits.  The grid has 2^15 cells along each axis of the scene; where
-        // the cells are not small against the leaf boxes (a very large scene of small triangles) the widened boxes
-        // cost more triangle tests than the smaller nodes save (measured: DESIGN.md section 4.1).
         double infl = 1.0;
-        const int mode = qn_env();
+        const int mode = qnodes_mode();
         lrc::QGrid g;
         if (mode != 0 && lrc::make_qgrid(h, s->qbase, s->qW, s->qinvW, g) && lrc::build_qnodes(h, g, q8, n16, &infl) &&
             (mode >= 2 || infl <= lrc::kQnodeMaxInflation)) {
-            const char* we = std::getenv("LRC_WIDE");
-            if (we && std::atoi(we) != 0 && !lrc::build_q4nodes(h, g, q16, n32, &s->num_nodes4)) { q16.clear(); n32.clear(); }
+#ifdef LRC_VARIANTS
+            if (env_int("LRC_WIDE", 0) != 0 && !lrc::build_q4nodes(h, g, q16, n32, &s->num_nodes4)) { q16.clear(); n32.clear(); }
+#endif
             if ((rc = upload((void**)&s->d_nodes_q, q8.data(), q8.size() * 4)) ||
                 (rc = upload((void**)&s->d_nodes_n, n16.data(), n16.size() * 4)) ||
                 (rc = upload((void**)&s->d_nodes_q4, q16.data(), q16.size() * 4)) ||
@@ -1332,14 +1399,66 @@ int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32
         }
         in.quantised_nodes = s->d_nodes_q ? 1u : 0u;
         in.leaf_inflation = (float)infl;
-        if (std::getenv("LRC_QNODES_VERBOSE"))
-            std::fprintf(stderr, "[qnodes] leaf box inflation %.3f, W = %g %g %g -> %s\n", infl, (double)s->qW[0],
-                         (double)s->qW[1], (double)s->qW[2], s->d_nodes_q ? "quantised images" : "float32 nodes");
+        qnodes_report(s, infl);
     }
     auto t2 = std::chrono::steady_clock::now();
     in.upload_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
     *out_scene = s;
     return LRC_OK;
+}
+
+// LRC_DEVICE_BUILD: 1 (default) = build the scene on the GPU, 0 = host builder (same tree, same bytes; the reference
+// for the device builder in the tests).  The four-wide images of the laboratory build exist on the host path only.
+bool want_device_build() {
+#ifdef LRC_VARIANTS
+    if (env_int("LRC_WIDE", 0) != 0) return false;
+#endif
+    return env_int("LRC_DEVICE_BUILD", 1) != 0;
+}
+
+}  // namespace
+
+int lrc_scene_create(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint32_t* tris3, uint64_t T,
+                     const uint16_t* tri_sem, const uint16_t* tri_ins, lrc_scene** out_scene) {
+    if (!out_scene) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: out_scene is NULL");
+    *out_scene = nullptr;
+    if (!ctx) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: ctx is NULL");
+    if ((V && !verts3) || (T && !tris3))
+        return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: NULL vertex or triangle array");
+    if (T >= (1ull << 28) || V >= (1ull << 32))
+        return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create: mesh too large (T < 2^28, V < 2^32)");
+    LRC_HIP(hipSetDevice(ctx->device));
+    if (want_device_build()) {
+        const int rc = scene_create_device(ctx, verts3, V, tris3, T, tri_sem, tri_ins, false, out_scene);
+        if (rc != lrc::kDevBuildUnsupported) return rc;
+    }
+    return scene_create_host(ctx, verts3, V, tris3, T, tri_sem, tri_ins, out_scene);
+}
+
+int lrc_scene_create_dev(lrc_ctx* ctx, const float* d_verts3, uint64_t V, const uint32_t* d_tris3, uint64_t T,
+                         const uint16_t* d_tri_sem, const uint16_t* d_tri_ins, lrc_scene** out_scene) {
+    if (!out_scene) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create_dev: out_scene is NULL");
+    *out_scene = nullptr;
+    if (!ctx) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create_dev: ctx is NULL");
+    if ((V && !d_verts3) || (T && !d_tris3))
+        return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create_dev: NULL vertex or triangle array");
+    if (T >= (1ull << 28) || V >= (1ull << 32))
+        return fail(LRC_ERR_INVALID_ARG, "lrc_scene_create_dev: mesh too large (T < 2^28, V < 2^32)");
+    LRC_HIP(hipSetDevice(ctx->device));
+    if (want_device_build()) {
+        const int rc = scene_create_device(ctx, d_verts3, V, d_tris3, T, d_tri_sem, d_tri_ins, true, out_scene);
+        if (rc != lrc::kDevBuildUnsupported) return rc;
+    }
+    // a mesh the device builder does not take (a handful of triangles), or LRC_DEVICE_BUILD=0: build on the host
+    std::vector<float> hv(3 * V);
+    std::vector<uint32_t> ht(3 * T);
+    std::vector<uint16_t> hs(d_tri_sem ? T : 0), hi(d_tri_ins ? T : 0);
+    if (V) LRC_HIP(hipMemcpy(hv.data(), d_verts3, 3 * V * 4, hipMemcpyDeviceToHost));
+    if (T) LRC_HIP(hipMemcpy(ht.data(), d_tris3, 3 * T * 4, hipMemcpyDeviceToHost));
+    if (d_tri_sem && T) LRC_HIP(hipMemcpy(hs.data(), d_tri_sem, T * 2, hipMemcpyDeviceToHost));
+    if (d_tri_ins && T) LRC_HIP(hipMemcpy(hi.data(), d_tri_ins, T * 2, hipMemcpyDeviceToHost));
+    return scene_create_host(ctx, hv.data(), V, ht.data(), T, d_tri_sem ? hs.data() : nullptr,
+                             d_tri_ins ? hi.data() : nullptr, out_scene);
 }
 
 int lrc_scene_get_info(const lrc_scene* scene, lrc_scene_info* out_info) {
@@ -1371,6 +1490,29 @@ int lrc_scene_export_bvh(const lrc_scene* s, float* nodes16, uint32_t* slot_prim
         LRC_HIP(hipMemcpy(nodes16, s->d_nodes, s->info.num_nodes * 64, hipMemcpyDeviceToHost));
     if (slot_prim && s->info.num_slots)
         LRC_HIP(hipMemcpy(slot_prim, s->d_slot_prim, s->info.num_slots * 4, hipMemcpyDeviceToHost));
+    return LRC_OK;
+}
+
+int lrc_scene_export_array(const lrc_scene* s, int which, void* dst, uint64_t dst_bytes, uint64_t* out_bytes) {
+    if (!s) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_export_array: scene is NULL");
+    const void* src = nullptr;
+    uint64_t bytes = 0;
+    const lrc_scene_info& in = s->info;
+    switch (which) {
+        case LRC_ARRAY_NODES: src = s->d_nodes; bytes = in.num_nodes * 64; break;
+        case LRC_ARRAY_TRIS: src = s->d_tris; bytes = in.num_slots * 48; break;
+        case LRC_ARRAY_SLOT_PRIM: src = s->d_slot_prim; bytes = in.num_slots * 4; break;
+        case LRC_ARRAY_SLOT_LABEL: src = s->d_slot_label; bytes = in.num_slots * 4; break;
+        case LRC_ARRAY_PRIM_PLANE: src = s->d_prim_plane; bytes = in.num_triangles * 32; break;
+        case LRC_ARRAY_NODES_Q: src = s->d_nodes_q; bytes = s->d_nodes_q ? in.num_nodes * 32 : 0; break;
+        case LRC_ARRAY_NODES_N: src = s->d_nodes_n; bytes = s->d_nodes_n ? in.num_nodes * 64 : 0; break;
+        default: return fail(LRC_ERR_INVALID_ARG, "lrc_scene_export_array: unknown array");
+    }
+    if (out_bytes) *out_bytes = bytes;
+    if (!dst || !bytes) return LRC_OK;
+    if (dst_bytes < bytes) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_export_array: destination too small");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    LRC_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return LRC_OK;
 }
 
@@ -1425,6 +1567,12 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
         const lrc_grid& g = *s->cur_grid;
         SectorParams q{};
         q.tp = p;
+        if (!s->d_slot_sphere && s->info.num_slots) {
+            LRC_HIP(hipMalloc((void**)&s->d_slot_sphere, s->info.num_slots * 16));
+            s->info.device_bytes += s->info.num_slots * 16;
+            hipLaunchKernelGGL(slot_sphere_kernel, dim3((uint32_t)((s->info.num_slots + kBlock - 1) / kBlock)), dim3(kBlock),
+                               0, st, (const float4*)s->d_tris, (uint32_t)s->info.num_slots, s->d_slot_sphere);
+        }
         q.slot_sphere = s->d_slot_sphere;
         q.H = g.lines; q.W = g.width;
         static const int nl_env = [] { const char* e = std::getenv("LRC_SECTOR_LINES"); return e ? std::atoi(e) : 0; }();

@@ -35,6 +35,7 @@ struct BuildOptions {
     int bfs_nodes = 2048;       // nodes laid out breadth-first at the front (the part all rays share)
     int threads   = 0;          // 0 = min(hardware threads, 16)
     int depth_slack = 2;        // >= 0: leaf depth <= balanced-tree height + slack; -1: only the hard cap (31)
+    int median_only = 0;        // test hook: every split is the median fallback (exercises that path in both builders)
 };
 
 // verts3: V x 3 float32, tris3: T x 3 uint32 (validated by the caller).  Deterministic.

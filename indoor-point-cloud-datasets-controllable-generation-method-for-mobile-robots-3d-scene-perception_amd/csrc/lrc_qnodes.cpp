@@ -17,8 +17,12 @@ namespace lrc {
 // world-space nodes.  Returns false (no images; the float32 nodes are used) when a scene does not fit.
 bool make_qgrid(const HostBVH& h, float base[3], float W[3], float invW[3], QGrid& g) {
     if (h.num_nodes == 0) return false;
+    return make_qgrid_bounds(h.bounds_lo, h.bounds_hi, base, W, invW, g);
+}
+
+bool make_qgrid_bounds(const float blo[3], const float bhi[3], float base[3], float W[3], float invW[3], QGrid& g) {
     for (int a = 0; a < 3; ++a) {
-        const double lo = h.bounds_lo[a], hi = h.bounds_hi[a];
+        const double lo = blo[a], hi = bhi[a];
         if (!(hi >= lo)) return false;
         int k = -20;                                                 // W = 2^k, 2^-20 <= W <= 2^16
         while (k <= 16 && 2.0 * std::ldexp(1.0, k) * (1.0 - 1.0 / 1024) < (hi - lo)) ++k;

@@ -25,6 +25,8 @@ struct QGrid { double Wd[3], bd[3]; };        // per axis: cell width * 2^14 (a 
 
 // the grid of a tree: base / W / 1/W as the kernel takes them.  false: the scene does not fit a grid
 bool make_qgrid(const HostBVH& h, float base[3], float W[3], float invW[3], QGrid& g);
+// the same from the scene bounds alone (the device builder has no HostBVH)
+bool make_qgrid_bounds(const float lo[3], const float hi[3], float base[3], float W[3], float invW[3], QGrid& g);
 
 // 32-byte nodes (8 words per node) and the same boxes as normalised float32 (16 floats per node)
 bool build_qnodes(const HostBVH& h, const QGrid& g, std::vector<uint32_t>& q8, std::vector<float>& n16,

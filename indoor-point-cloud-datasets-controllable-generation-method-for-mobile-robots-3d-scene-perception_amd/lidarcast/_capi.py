@@ -23,7 +23,7 @@ LRC_INVALID_PRIM = 0xFFFFFFFF
 SYMBOLS = (
     "lrc_version", "lrc_last_error", "lrc_device_count",
     "lrc_ctx_create", "lrc_ctx_destroy", "lrc_ctx_synchronize",
-    "lrc_scene_create", "lrc_scene_destroy", "lrc_scene_get_info", "lrc_scene_export_bvh",
+    "lrc_scene_create", "lrc_scene_create_dev", "lrc_scene_destroy", "lrc_scene_get_info", "lrc_scene_export_bvh", "lrc_scene_export_array",
     "lrc_scene_get_counters", "lrc_scene_set_options", "lrc_scene_get_occupancy",
     "lrc_cast", "lrc_cast_dev", "lrc_cast_segments", "lrc_cast_segments_dev",
     "lrc_scan_poses", "lrc_scan_poses_dev", "lrc_scan_poses_compact", "lrc_host_alloc", "lrc_host_free",
@@ -50,7 +50,8 @@ class LrcSceneInfo(C.Structure):
                 ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32),
                 ("device_bytes", C.c_uint64), ("build_ms", C.c_double), ("upload_ms", C.c_double),
                 ("bounds_lo", C.c_float * 3), ("bounds_hi", C.c_float * 3),
-                ("quantised_nodes", C.c_uint32), ("leaf_inflation", C.c_float)]
+                ("quantised_nodes", C.c_uint32), ("leaf_inflation", C.c_float),
+                ("device_build", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class LrcScanOptions(C.Structure):
@@ -106,9 +107,11 @@ def load():
         "lrc_ctx_destroy": [vp],
         "lrc_ctx_synchronize": [vp],
         "lrc_scene_create": [vp, vp, u64, vp, u64, vp, vp, C.POINTER(vp)],
+        "lrc_scene_create_dev": [vp, vp, u64, vp, u64, vp, vp, C.POINTER(vp)],
         "lrc_scene_destroy": [vp],
         "lrc_scene_get_info": [vp, C.POINTER(LrcSceneInfo)],
         "lrc_scene_export_bvh": [vp, vp, vp],
+        "lrc_scene_export_array": [vp, i32, vp, u64, C.POINTER(u64)],
         "lrc_scene_get_counters": [vp, C.POINTER(u64), C.POINTER(u64)],
         "lrc_scene_set_options": [vp, C.POINTER(LrcScanOptions)],
         "lrc_scene_get_occupancy": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],

@@ -336,6 +336,40 @@ class Scene:
         check(self._lib.lrc_scene_export_bvh(self._h, _ptr(nodes), _ptr(slot_prim)), "lrc_scene_export_bvh")
         return nodes, slot_prim
 
+    ARRAYS = {"nodes": 0, "tris": 1, "slot_prim": 2, "slot_label": 3, "prim_plane": 4, "nodes_q": 5, "nodes_n": 6}
+
+    def export_array(self, name):
+        """Raw bytes (uint8) of one of the scene's device arrays; empty when the scene has no such array."""
+        which = self.ARRAYS[name]
+        nbytes = C.c_uint64(0)
+        check(self._lib.lrc_scene_export_array(self._h, which, None, 0, C.byref(nbytes)), "lrc_scene_export_array")
+        out = np.zeros(int(nbytes.value), dtype=np.uint8)
+        if out.size:
+            check(self._lib.lrc_scene_export_array(self._h, which, _ptr(out), out.size, None), "lrc_scene_export_array")
+        return out
+
+    @classmethod
+    def from_device(cls, ctx, verts_t, tris_t, sem_t=None, ins_t=None):
+        """Scene from a mesh that is already in HBM (torch CUDA tensors: float32 (V,3), int32/uint32 (T,3), optional
+        int16/uint16 (T,) labels): lrc_scene_create_dev, nothing crosses PCIe."""
+        self = cls.__new__(cls)
+        self._lib = _capi.load()
+        self.ctx = ctx
+        if verts_t.dim() != 2 or verts_t.shape[1] != 3 or tris_t.dim() != 2 or tris_t.shape[1] != 3:
+            raise ValueError("vertices must be (V, 3) and triangles (T, 3)")
+        if verts_t.element_size() != 4 or tris_t.element_size() != 4 or not verts_t.is_contiguous() or not tris_t.is_contiguous():
+            raise ValueError("device meshes must be contiguous float32 vertices and 32-bit triangle rows")
+        for lab in (sem_t, ins_t):
+            if lab is not None and (lab.element_size() != 2 or lab.numel() != tris_t.shape[0] or not lab.is_contiguous()):
+                raise ValueError("per-triangle labels must be contiguous 16-bit arrays of shape (T,)")
+        h = C.c_void_p()
+        dp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        check(self._lib.lrc_scene_create_dev(ctx._h, dp(verts_t), verts_t.shape[0], dp(tris_t), tris_t.shape[0],
+                                             dp(sem_t), dp(ins_t), C.byref(h)), "lrc_scene_create_dev")
+        self._h = h
+        self.num_vertices, self.num_triangles = int(verts_t.shape[0]), int(tris_t.shape[0])
+        return self
+
     # ---- host arrays ----------------------------------------------------------------------------
     @staticmethod
     def _alloc(n, want):

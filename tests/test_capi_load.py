@@ -39,7 +39,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(LrcCompactIO) == 14 * 8
     assert [n for n, _ in LrcFrames._fields_] == header_fields("lrc_frames")
     assert C.sizeof(LrcFrames) == 12 * 8
-    assert C.sizeof(LrcSceneInfo) == 5 * 8 + 2 * 4 + 8 + 2 * 8 + 6 * 4 + 2 * 4
+    assert [n for n, _ in LrcSceneInfo._fields_] == header_fields("lrc_scene_info")
+    assert C.sizeof(LrcSceneInfo) == 5 * 8 + 2 * 4 + 8 + 2 * 8 + 6 * 4 + 4 * 4
 
 
 def test_no_gpu_means_loud_failure():

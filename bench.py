@@ -8,9 +8,13 @@ One "step" = one pass of the hot path over the whole trajectory batch, inputs re
   rebuild of the whole scene cloud on every GPU.
 Weak scaling: every rank scans its own 64 poses of a 64*N-pose trajectory over a replica of the scene.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the trace kernel with the algorithmic bytes per ray
-of SURVEY.md section 8(d); `cpu_baseline` times the CPU oracle (a restatement: Open3D/Embree, the
-reference's CPU path, is not installed) on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0).  `roofline` prices the trace kernel against the roof that binds it -- vector-ALU issue
+under divergence (lane-operations that did work / peak lane-operations), from the committed counter profile of this
+binary and the kernel time measured live -- and reports the second, equally loaded pipe (the CU's vector-memory return
+path) and the HBM-side traffic beside it; SURVEY.md section 8(d)'s per-ray byte model is kept as a labelled side field
+only (it is not a lower bound on traffic).  `cpu_baseline` times the CPU oracle (a restatement: Open3D/Embree, the
+reference's CPU path, is not installed) on a bounded sample of the same workload.  `config.scene_create_ms` is what
+the scene costs before the first ray: mesh in host memory -> BVH resident in HBM, built on the GPU.
 """
 import argparse
 import json
@@ -57,19 +61,22 @@ def pmc_profile(kernel_prefix, rays_per_launch, scene):
     counts of a launch (instructions, active lanes, bytes) are properties of binary + workload, not of the box; the
     TIME they are divided by is measured live in this run."""
     import __graft_entry__ as entry
-    path = os.path.join(REPO, "profiles", "pmc_latest.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if (t.get("source_sha256") != entry.source_fingerprint() or t.get("rays_per_launch") != rays_per_launch
-                or t.get("scene") != scene or not t["kernel"].startswith(kernel_prefix)):
-            return None
-        c = t["counters"]
-        for k in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "FETCH_SIZE", "WRITE_SIZE"):
-            float(c[k])
-        return c
-    except (OSError, KeyError, ValueError, TypeError):
-        return None
+    fp = entry.source_fingerprint()
+    # one file per scene (tools/pmc.sh with PMC_SCENE), pmc_latest.json = the headline scene
+    for name in (f"pmc_{scene}.json", "pmc_latest.json"):
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                t = json.load(f)
+            if (t.get("source_sha256") != fp or t.get("rays_per_launch") != rays_per_launch
+                    or t.get("scene") != scene or not t["kernel"].startswith(kernel_prefix)):
+                continue
+            c = t["counters"]
+            for k in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+                float(c[k])
+            return c
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None
 
 
 def c3_sensor():
@@ -219,8 +226,20 @@ def main():
     # ---- scene (replicated) and inputs, resident in HBM before the timed region ----
     mesh = synth.make_scene(args.scene)
     ctx = lidarcast.Context(local_rank)
-    scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
+    v32 = np.ascontiguousarray(mesh.vertices, dtype=np.float32)
+    f32 = np.ascontiguousarray(mesh.triangles, dtype=np.uint32)
+    t0 = time.perf_counter()
+    scene = lidarcast.Scene(ctx, v32, f32, mesh.triangle_sem, mesh.triangle_ins)
+    create_first_ms = (time.perf_counter() - t0) * 1e3      # includes the builder's one-time scratch allocation
     info = scene.info
+    create_ms = []
+    if rank == 0:
+        for _ in range(3):                                   # steady state: the next mesh of a batch
+            t0 = time.perf_counter()
+            again = lidarcast.Scene(ctx, v32, f32, mesh.triangle_sem, mesh.triangle_ins)
+            create_ms.append((time.perf_counter() - t0) * 1e3)
+            again_info = again.info
+            again.close()
     sensor = c3_sensor()
     if args.virtual_world > 1 and not (args.dist_selftest and world == 1):
         raise SystemExit("--virtual-world needs --dist-selftest on one GPU")
@@ -395,6 +414,19 @@ def main():
             "frac": achieved / VALU_PEAK_GLANEOPS, "traffic": traffic,
             "valu_issue_frac": issue_frac, "lane_utilisation": lane_util,
             "valu_wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "active_lane_ops_per_launch": lane_ops,
+            # the second, about equally loaded pipe: a wave-wide vector load returns through the CU's 64 B/clk path --
+            # 16 clocks for a dwordx4 (the node and triangle fetches), less for narrower loads, so this is an upper bound
+            "second_roof": {
+                "pipe": "vector-memory return path (64 B/clk/CU)",
+                "vmem_rd_wave_instructions_per_launch": pmc.get("SQ_INSTS_VMEM_RD"),
+                "busy_frac_upper_bound": (pmc["SQ_INSTS_VMEM_RD"] * 16.0 / (256 * CLOCK_GHZ * 1e9 * kernel_s))
+                if "SQ_INSTS_VMEM_RD" in pmc else None,
+                "wave_cycles_waiting_frac": (pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"])
+                if "SQ_WAIT_ANY" in pmc and pmc.get("SQ_WAVE_CYCLES") else None,
+                "salu_per_valu": (pmc["SQ_INSTS_SALU"] / pmc["SQ_INSTS_VALU"]) if "SQ_INSTS_SALU" in pmc else None,
+                "note": "SQ_INSTS_VMEM_RD x 16 clk / (256 CU x 2.4 GHz x kernel time): every vector load priced as a "
+                        "dwordx4; SQ_WAIT_ANY / SQ_WAVE_CYCLES = share of resident-wave cycles spent waiting",
+            },
             "hbm_side": {"traffic_GBps": traffic / kernel_s / 1e9, "frac_of_hbm_peak": traffic / kernel_s / 1e9 / HBM_PEAK_GBS,
                          "note": "2 x FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction of MI355X_MICROARCH.md); "
                                  "FETCH counts fabric requests the 256 MiB Infinity Cache mostly serves"},
@@ -431,7 +463,16 @@ def main():
                 **({"virtual_world": job} if world == 1 and job > 1 else {}),
                 "rays_per_step_per_gpu": n, "hit_fraction": hits_total / (n * (job if dist_path else 1)),
                 "bvh": {"nodes": info["num_nodes"], "depth": info["max_depth"],
-                        "build_ms": round(info["build_ms"], 1), "device_MB": round(info["device_bytes"] / 1e6, 1)},
+                        "builder": "device" if info["device_build"] else "host",
+                        "build_ms": round(again_info["build_ms"], 2), "transfer_ms": round(again_info["upload_ms"], 2),
+                        "device_MB": round(info["device_bytes"] / 1e6, 1)},
+                "scene_create_ms": round(float(np.median(create_ms)), 2),
+                "scene_create_first_ms": round(create_first_ms, 2),
+                "scene_create_note": "lrc_scene_create: float32 mesh in (pageable) host memory -> validated, BVH + triangle "
+                                     "records + quantised node images resident in HBM, built on the GPU "
+                                     "(csrc/lrc_bvh_device.hip); median of 3 re-creations, first = with the builder's "
+                                     "one-time scratch allocation.  The reference pays an Embree build per POSE",
+                "trajectory_including_scene_create_rays_per_s": n / (float(np.median(create_ms)) * 1e-3 + elapsed / args.steps),
                 "caller_path_note": "value is the device-resident loop; caller_path_rays_per_s is what a host caller of "
                                     "the plugin surface gets (kept rows in page-locked host memory, PCIe included)",
                 "step": "in-kernel ray generation + BVH traversal + hit write-back (36 B/ray) + "

@@ -329,6 +329,23 @@ int lrc_scan_rays_compact(lrc_scene* scene, const float* rays6, const uint8_t* k
                           uint64_t num_poses, uint64_t rays_per_pose, double max_range, const lrc_frames* out,
                           uint64_t capacity, uint64_t* out_total);
 
+/* ---- numpy's legacy seeded stream (row a7: the BLK2GO generator draws its noise from np.random) --------------------
+ * The reference draws, per pose, two normals per ray and then one uniform per ray from the GLOBAL numpy stream
+ * (lidar/indoor_lidar.py:257-296).  lrc_rng_scan_draws produces exactly the doubles RandomState.normal(loc, scale,
+ * normals_per_pose) followed by RandomState.random_sample(uniforms_per_pose) would return, pose after pose, for
+ * num_poses poses, and leaves *state where numpy's generator would stand (np.random.get_state() / set_state()
+ * tuples map to this struct field by field): MT19937 words, random_sample doubles, polar-method normals with the
+ * cached second value.  Host code, multi-threaded (threads <= 0: the cores of the host, at most 16); no GPU involved. */
+typedef struct lrc_mt19937_state {
+    uint32_t key[624];
+    int32_t  pos;          /* 0..624, next word of key[] (624: the block is used up)              */
+    int32_t  has_gauss;
+    double   gauss;        /* the cached normal when has_gauss                                   */
+} lrc_mt19937_state;
+int lrc_rng_scan_draws(lrc_mt19937_state* state, uint64_t num_poses, uint64_t normals_per_pose,
+                       uint64_t uniforms_per_pose, double loc, double scale, double* out_normals,
+                       double* out_uniforms, int threads);
+
 /* ---- diagnostics ---------------------------------------------------------------------------------------
  * Per-ray traversal counters of a pose-batched scan from an instrumented build of the trace kernel, host arrays.
  * stats: (num_poses * rays_per_pose, LRC_STATS_WORDS) uint32: [0] inner-node steps, [1] triangle tests, [2] node steps

@@ -112,6 +112,7 @@ struct lrc_scene {
     float4* d_tris = nullptr;
     uint32_t* d_slot_prim = nullptr;
     uint32_t* d_slot_label = nullptr;
+    float* d_slot_box = nullptr;      // LRC_EDGE_TRIS: per leaf slot the triangle's exact vertex box (lo xyz, hi xyz)
     float4* d_prim_plane = nullptr;   // per caller's triangle row: (v0, label bits), (Ng, 0): lrc_cloud_from_prims_dev
     float4* d_slot_sphere = nullptr;  // per leaf slot: centre of the triangle's box + bounding radius (sector_kernel)
     // quantised node images of the SAME tree ("32-byte nodes"): child boxes on a 15-bit grid
@@ -157,6 +158,7 @@ struct TraceParams {
     const float4* tris;
     const uint32_t* slot_prim;
     const uint32_t* slot_label;
+    const float* slot_box;     // LRC_EDGE_TRIS: per slot lo xyz, hi xyz of the triangle's vertices
     const float4* prim_plane;  // per caller's triangle row: (v0, label bits), (Ng, 0)
     uint32_t num_nodes;
     const uint4* nodes_q;      // QN kernels: 32-byte quantised nodes (per-lane fetches) ...
@@ -432,9 +434,11 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
     // the plane selectors are wave-uniform and live in SGPRs.  2: the same on the four-wide collapse of the tree.
     bool redo = false;         // quantised paths: this ray must be redone on qtag 0 (its closest candidate failed the box
                                // clause, or -- qtag 2 -- its stack would not have held a step's pushes)
-    auto traverse = [&](auto qtag) {
+    auto traverse = [&](auto qtag, auto ctag) {
         constexpr int QM = decltype(qtag)::value;
         constexpr bool Q = QM != 0;
+        constexpr bool INLINE_CLAUSE = decltype(ctag)::value != 0;    // LRC_EDGE_TRIS: the redo route tests the clause per test
+        (void)INLINE_CLAUSE;
         RaySlab sl;
         uint32_t sel_nx = 0, sel_ny = 0, sel_nz = 0, sel_fx = 0, sel_fy = 0, sel_fz = 0;
         if (Q) {
@@ -505,6 +509,7 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
             interval(b, n1, f1);
             choose(n0, f0, n1, f1, (int)a.w, (int)b.w);
         };
+#ifdef LRC_VARIANTS
         // four-wide step: descend into the nearest hit child, push the other hit children; nothing hit -> pop
         auto choose4 = [&](float t0, float f0, float t1, float f1, float t2, float f2, float t3, float f3,
                            int r0, int r1, int r2, int r3) {
@@ -560,6 +565,7 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
             choose4(t0, f0, t1, f1, t2, f2, t3, f3, __float_as_int(a1.z), __float_as_int(b1.z), __float_as_int(c1.z),
                     __float_as_int(e1.z));
         };
+#endif
         // one leaf: test its 1..4 triangles, keep the lexicographically smallest (t, triangle row)
         auto leaf = [&](const int lref) {
             const uint32_t enc = (uint32_t)(~lref);
@@ -582,7 +588,22 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
                         const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
                         float t;
                         bool hit;
+#ifdef LRC_EDGE_TRIS
+                        // edge records (v0, e1, e2, Ng): v1 / v2 above ARE e1 / e2.  Candidates are ranked by the
+                        // Moeller-Trumbore conditions on every node image; the box clause is tested once, after the
+                        // traversal (below), and inline only on the redo route (INLINE_CLAUSE, float32 nodes).
+                        hit = tri_mt_e(o, d, v0, v1, v2, ng, t);
+                        if (INLINE_CLAUSE) {
+                            if (hit) {
+                                const float* bx = p.slot_box + (size_t)slot * 6;
+                                hit = box_clause(sl, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], t);
+                                if (STATS) { if (!hit) st_pad += 1u; }
+                            }
+                        }
+                        if (false) {
+#else
                         if (Q) {
+#endif
                             // Candidates are ranked by the Moeller-Trumbore conditions alone; the definition's box
                             // clause (world coordinates) is tested once, after the traversal, on the closest candidate.
                             // If that candidate passes, it is the definition's closest hit: every triangle passing both
@@ -606,46 +627,18 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
             }
         };
         auto fetch_step = [&]() {         // per-lane fetch of node `ref`
+#ifdef LRC_VARIANTS
             if (QM == 2) {
                 const uint4* n = p.nodes_q4 + (size_t)ref * 4;
-#ifdef LRC_EXP_TIMING
-                if (STATS) {
-                    const uint64_t c0 = __builtin_amdgcn_s_memtime();
-                    const uint4 a = n[0], b = n[1], c = n[2], e = n[3];
-                    asm volatile("s_waitcnt vmcnt(0)" :: "v"(a.x), "v"(b.x), "v"(c.x), "v"(e.x));
-                    st_uni += (uint32_t)(__builtin_amdgcn_s_memtime() - c0);
-                    step_q4(a, b, c, e);
-                    return;
-                }
-#endif
                 step_q4(n[0], n[1], n[2], n[3]);
-            } else if (Q) {
-                const uint4* n = p.nodes_q + (size_t)ref * 2;
-#ifdef LRC_EXP_TIMING      // measurement build only (tools/trav_timing.py): cycles a wave waits for a per-lane node fetch
-                if (STATS) {
-                    const uint64_t c0 = __builtin_amdgcn_s_memtime();
-                    const uint4 a = n[0], b = n[1];
-                    asm volatile("s_waitcnt vmcnt(0)" :: "v"(a.x), "v"(b.x));
-                    st_uni += (uint32_t)(__builtin_amdgcn_s_memtime() - c0);
-                    step_q(a, b);
-                    return;
-                }
+            } else
 #endif
+            if (Q) {
+                const uint4* n = p.nodes_q + (size_t)ref * 2;
                 step_q(n[0], n[1]);
             } else {
                 const F4* n = (const F4*)(p.nodes + (size_t)ref * 4);
-#ifdef LRC_EXP_EXTRA_NODE_LOADS      // measurement build only (tools/extra_load_experiment.sh): N more 16-byte loads of this line
-                typedef float xv4f __attribute__((ext_vector_type(4)));
-                xv4f sink[LRC_EXP_EXTRA_NODE_LOADS];
-#pragma unroll
-                for (int x = 0; x < LRC_EXP_EXTRA_NODE_LOADS; ++x)
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink[x]) : "v"(n + (x & 3)));
-#endif
                 step(n[0], n[1], n[2], n[3]);
-#ifdef LRC_EXP_EXTRA_NODE_LOADS
-#pragma unroll
-                for (int x = 0; x < LRC_EXP_EXTRA_NODE_LOADS; ++x) asm volatile("s_waitcnt vmcnt(0)" :: "v"(sink[x]));
-#endif
             }
         };
         while (true) {
@@ -659,11 +652,14 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
                     const int uref = __builtin_amdgcn_readfirstlane(ref);
                     if (__builtin_amdgcn_ballot_w64(ref != uref) == 0ull) {
                         if (STATS) st_uni += 1u;
+#ifdef LRC_VARIANTS
                         if (QM == 2) {
                             const float4* n = p.nodes_n4 + (size_t)uref * 8;
                             step_n4(ld_uniform(n), ld_uniform(n + 1), ld_uniform(n + 2), ld_uniform(n + 3),
                                     ld_uniform(n + 4), ld_uniform(n + 5), ld_uniform(n + 6), ld_uniform(n + 7));
-                        } else {
+                        } else
+#endif
+                        {
                             const float4* n = (Q ? p.nodes_n : p.nodes) + (size_t)uref * 4;
                             step(ld_uniform(n), ld_uniform(n + 1), ld_uniform(n + 2), ld_uniform(n + 3));
                         }
@@ -689,6 +685,25 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
             --sp;
             ref = s_stack[sp * kTBlock + tid];
         }
+#ifdef LRC_EDGE_TRIS
+        if (!INLINE_CLAUSE) {
+            if (best_slot != 0xFFFFFFFFu) {       // the box clause of the closest candidate, in world coordinates
+                const float* bx = p.slot_box + (size_t)best_slot * 6;
+                RaySlab w = sl;
+                if (Q) {        // ix = ix' / W exactly (W a power of two); ox = o * ix as make_slab forms it
+                    w.ix = sl.ix * p.qinvW[0]; w.iy = sl.iy * p.qinvW[1]; w.iz = sl.iz * p.qinvW[2];
+                    w.ox = o.x * w.ix; w.oy = o.y * w.iy; w.oz = o.z * w.iz;
+                }
+                if (!box_clause(w, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], tbest)) {
+                    redo = true;
+                    if (STATS) st_pad += 1u;
+                }
+            }
+#ifdef LRC_VARIANTS
+            if (p.force_redo) redo |= (gid % p.force_redo) == 0;      // test hook (LRC_DEBUG_FORCE_REDO=m)
+#endif
+        }
+#else
         if (Q) {
             if (best_slot != 0xFFFFFFFFu) {       // the box clause of the closest candidate, in world coordinates
                 const float4* tr = p.tris + (size_t)best_slot * 3;
@@ -702,12 +717,16 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
                     if (STATS) st_pad += 1u;
                 }
             }
-            if (p.force_redo) redo |= (gid % p.force_redo) == 0;
+#ifdef LRC_VARIANTS
+            if (p.force_redo) redo |= (gid % p.force_redo) == 0;      // test hook (LRC_DEBUG_FORCE_REDO=m)
+#endif
         }
+#endif
     };
-#ifdef LRC_EXP_TIMING
-    const uint64_t t_begin = __builtin_amdgcn_s_memtime();
-    const uint64_t r_begin = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+#ifdef LRC_EDGE_TRIS
+    using FirstPass = IntTag<0>;      // edge records: every first pass defers the box clause
+#else
+    using FirstPass = IntTag<1>;      // vertex records: the float32 nodes test the clause per triangle (tri_hit)
 #endif
     if (p.num_nodes) {
         if (QN) {
@@ -720,27 +739,31 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
             const bool far = live & (far1(o.x, d.x, p.qbase[0], p.qW[0]) | far1(o.y, d.y, p.qbase[1], p.qW[1]) |
                                      far1(o.z, d.z, p.qbase[2], p.qW[2]));
             const uint32_t oct = sign_octant(d);
-            const uint32_t oct0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)oct);     // of the first live lane
+            // octant of the first ACTIVE lane (which may be a ray that is not cast: the wave then merely takes the float32
+            // nodes; results do not depend on the choice)
+            const uint32_t oct0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)oct);
             // a wave whose rays point into different octants (it straddles an axis direction) walks the float32 nodes too
-            if (__builtin_amdgcn_ballot_w64(far | (live & (oct != oct0))) != 0ull) { if (live) traverse(IntTag<0>{}); }
+            if (__builtin_amdgcn_ballot_w64(far | (live & (oct != oct0))) != 0ull) { if (live) traverse(IntTag<0>{}, FirstPass{}); }
             else if (live) {
-                if (QN == 2) traverse(IntTag<2>{});
-                else traverse(IntTag<1>{});
-            }
-            if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
-                if (redo) {
-                    tbest = __builtin_inff(); best_slot = 0xFFFFFFFFu; best_prim = 0xFFFFFFFFu;
-                    traverse(IntTag<0>{});
-                }
+#ifdef LRC_VARIANTS
+                if (QN == 2) traverse(IntTag<2>{}, IntTag<0>{});
+                else
+#endif
+                traverse(IntTag<1>{}, IntTag<0>{});
             }
         } else if (live) {
-            traverse(IntTag<0>{});
+            traverse(IntTag<0>{}, FirstPass{});
+        }
+        // a ray whose closest candidate failed the box clause (or, four-wide nodes, whose stack was too short) is redone
+        // on the float32 nodes with the clause tested per triangle
+        if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+            if (redo) {
+                tbest = __builtin_inff(); best_slot = 0xFFFFFFFFu; best_prim = 0xFFFFFFFFu;
+                traverse(IntTag<0>{}, IntTag<1>{});
+            }
         }
     }
 
-#ifdef LRC_EXP_TIMING
-    if (STATS) { st_dead = (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin); st_pad = (uint32_t)(__builtin_amdgcn_s_memrealtime() - r_begin); }
-#endif
     // ---- fused write-back ----
     if (GEN != 0) {
         // the range-filter centre (the pose's translation, float64) is fetched again here instead of being held in six
@@ -764,6 +787,7 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
 
 }
 
+#ifdef LRC_VARIANTS
 // ---- measured alternative: K rays per lane with private refill (LRC_REFILL=K) -------------
 // One wave owns K consecutive 64-ray tiles of a pose-batched scan; lane l traces rays l, 64+l, 128+l, ... one after the
 // other, starting its next ray the moment the current one is done instead of idling until the slowest lane of the wave
@@ -904,6 +928,7 @@ __global__ __launch_bounds__(kTBlock, W) void trace_refill_kernel(const TracePar
 }
 
 #include "lrc_sector.h"
+#endif   // LRC_VARIANTS
 #include "lrc_stats.h"
 
 // ---- compaction -------------------------------------------------------------------------------
@@ -1126,6 +1151,7 @@ __global__ __launch_bounds__(kBlock) void prim_scatter_kernel(const RebuildParam
     rebuild_tiles<R>(q, tile0, q.ntiles, threadIdx.x & 63u);
 }
 
+#ifdef LRC_VARIANTS
 // Bounding sphere of every triangle's axis-aligned box (centre and half diagonal, rounded up): what sector_kernel
 // tests against a packet of rays before it runs the exact ray/triangle test.  Built on first use of the packet kernel.
 __global__ __launch_bounds__(kBlock) void slot_sphere_kernel(const float4* __restrict__ tris, uint32_t num_slots,
@@ -1151,6 +1177,8 @@ __global__ __launch_bounds__(kBlock) void slot_sphere_kernel(const float4* __res
     const float r = (float)__builtin_sqrt(hd2);
     sphere[k] = make_float4(ctr[0], ctr[1], ctr[2], __uint_as_float(__float_as_uint(r) + 1u));    // nextafter(r, +inf), r >= 0
 }
+
+#endif   // LRC_VARIANTS
 
 }  // namespace
 
@@ -1228,6 +1256,7 @@ int lrc_scene_destroy(lrc_scene* s) {
         if (s->d_tris) (void)hipFree(s->d_tris);
         if (s->d_slot_prim) (void)hipFree(s->d_slot_prim);
         if (s->d_slot_label) (void)hipFree(s->d_slot_label);
+        if (s->d_slot_box) (void)hipFree(s->d_slot_box);
         if (s->d_prim_plane) (void)hipFree(s->d_prim_plane);
         if (s->d_nodes_q) (void)hipFree(s->d_nodes_q);
         if (s->d_nodes_n) (void)hipFree(s->d_nodes_n);
@@ -1243,20 +1272,18 @@ namespace {
 
 int env_int(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
 
-lrc::BuildOptions build_options_from_env() {
-    lrc::BuildOptions opt;
+void build_options_from_env(lrc::BuildOptions& opt) {
     opt.max_leaf = env_int("LRC_MAX_LEAF", opt.max_leaf);
     opt.bfs_nodes = env_int("LRC_BFS_NODES", opt.bfs_nodes);
     opt.depth_slack = env_int("LRC_DEPTH_SLACK", opt.depth_slack);
     opt.median_only = env_int("LRC_BUILD_MEDIAN_ONLY", 0);      // test hook: every split takes the median fallback
-    return opt;
 }
 
 // LRC_QNODES: 0 = float32 nodes only, 1 (default) = quantised images when the grid is fine enough for the scene's
 // triangles, 2 = whenever the grid fits.  The grid has 2^15 cells along each axis of the scene; where the cells are
 // not small against the leaf boxes (a very large scene of small triangles) the widened boxes cost more triangle tests
 // than the smaller nodes save (measured: DESIGN.md section 4.1).
-int qnodes_mode() { static const int m = env_int("LRC_QNODES", 1); return m; }
+int qnodes_mode() { return env_int("LRC_QNODES", 1); }      // read at every scene creation
 
 void qnodes_report(const lrc_scene* s, double infl) {
     if (std::getenv("LRC_QNODES_VERBOSE"))
@@ -1273,8 +1300,10 @@ int scene_create_device(lrc_ctx* ctx, const float* verts3, uint64_t V, const uin
     s->ctx = ctx;
     lrc::DeviceScene d;
     std::string err;
-    const int rc = lrc::build_bvh_device(&ctx->build_arena, verts3, V, tris3, T, tri_sem, tri_ins, on_device,
-                                         build_options_from_env(), qnodes_mode(), &d, &err);
+    lrc::BuildOptions opt;
+    build_options_from_env(opt);
+    const int rc = lrc::build_bvh_device(&ctx->build_arena, verts3, V, tris3, T, tri_sem, tri_ins, on_device, opt,
+                                         qnodes_mode(), &d, &err);
     if (rc != lrc::kDevBuildOk) {
         delete s;
         return rc < 0 ? fail(rc, err) : rc;
@@ -1284,6 +1313,7 @@ int scene_create_device(lrc_ctx* ctx, const float* verts3, uint64_t V, const uin
     s->d_tris = (float4*)d.tris;
     s->d_slot_prim = d.slot_prim;
     s->d_slot_label = d.slot_label;
+    s->d_slot_box = d.slot_box;
     s->d_prim_plane = (float4*)d.prim_plane;
     s->d_nodes_q = (uint4*)d.nodes_q;
     s->d_nodes_n = (float4*)d.nodes_n;
@@ -1325,7 +1355,8 @@ int scene_create_host(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint3
     s->ctx = ctx;
 
     lrc::HostBVH h;
-    const lrc::BuildOptions opt = build_options_from_env();
+    lrc::BuildOptions opt;
+    build_options_from_env(opt);
     auto t0 = std::chrono::steady_clock::now();
     try {
         lrc::build_bvh(verts3, V, tris3, T, tri_sem, tri_ins, opt, &h);
@@ -1370,7 +1401,8 @@ int scene_create_host(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint3
         (rc = upload((void**)&s->d_nodes, h.nodes.data(), h.nodes.size() * 4)) ||
         (rc = upload((void**)&s->d_tris, h.tri_rec.data(), h.tri_rec.size() * 4)) ||
         (rc = upload((void**)&s->d_slot_prim, h.slot_prim.data(), h.slot_prim.size() * 4)) ||
-        (rc = upload((void**)&s->d_slot_label, h.slot_label.data(), h.slot_label.size() * 4))) {
+        (rc = upload((void**)&s->d_slot_label, h.slot_label.data(), h.slot_label.size() * 4)) ||
+        (rc = upload((void**)&s->d_slot_box, h.slot_box.data(), h.slot_box.size() * 4))) {
         std::string keep = g_err;
         lrc_scene_destroy(s);
         g_err = keep;
@@ -1516,11 +1548,105 @@ int lrc_scene_export_array(const lrc_scene* s, int which, void* dst, uint64_t ds
     return LRC_OK;
 }
 
+#ifdef LRC_VARIANTS
+// Laboratory build (-DLRC_VARIANTS; tests/test_parity_gpu.py::test_kernel_variants_are_bit_identical, tools/): the measured
+// alternatives of DESIGN.md section 4.1, selected by environment variables.  Every one returns the product kernel's bytes.
+// Returns 1 when no variant is selected (the caller goes on with the product dispatch).
+static int launch_trace_lab(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, bool stats, uint64_t nblk, size_t lds,
+                            uint32_t depth) {
+    static const int force_redo = env_int("LRC_DEBUG_FORCE_REDO", 0);
+    static const int leafw = env_int("LRC_LEAFW", 1), uni = env_int("LRC_UNIFORM", 1), spec = env_int("LRC_SPEC", 0);
+    static const int sector = env_int("LRC_SECTOR", 1), refill = env_int("LRC_REFILL", 0);
+    p.force_redo = (uint32_t)force_redo;
+    const bool qn = s->d_nodes_q != nullptr, wide = s->d_nodes_q4 != nullptr;
+#define LRC_LAB(G, W, U, S, Q) \
+    hipLaunchKernelGGL((trace_kernel<G, W, U, S, false, Q>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p)
+#define LRC_LAB_PICK(G)                                                                              \
+    do {                                                                                             \
+        if (spec) { if (leafw == 2) LRC_LAB(G, 2, true, true, 0); else LRC_LAB(G, 1, true, true, 0); } \
+        else if (!uni) { if (leafw == 2) LRC_LAB(G, 2, false, false, 0); else LRC_LAB(G, 1, false, false, 0); } \
+        else if (leafw == 2) { if (qn) LRC_LAB(G, 2, true, false, 1); else LRC_LAB(G, 2, true, false, 0); }  \
+        else LRC_LAB(G, 1, true, false, 0);        /* not reached: the plain case is the product dispatch */ \
+    } while (0)
+    if (gen == 3 && sector && !stats) {
+        const lrc_grid& g = *s->cur_grid;
+        SectorParams q{};
+        q.tp = p;
+        if (!s->d_slot_sphere && s->info.num_slots) {
+            LRC_HIP(hipMalloc((void**)&s->d_slot_sphere, s->info.num_slots * 16));
+            s->info.device_bytes += s->info.num_slots * 16;
+            hipLaunchKernelGGL(slot_sphere_kernel, dim3((uint32_t)((s->info.num_slots + kBlock - 1) / kBlock)), dim3(kBlock),
+                               0, st, (const float4*)s->d_tris, (uint32_t)s->info.num_slots, s->d_slot_sphere);
+        }
+        q.slot_sphere = s->d_slot_sphere;
+        q.H = g.lines; q.W = g.width;
+        static const int nl_env = env_int("LRC_SECTOR_LINES", 0);
+        uint32_t nl = nl_env > 0 ? (uint32_t)nl_env : 8u;
+        if (nl > 8u) nl = 8u;
+        if (nl > g.lines) nl = g.lines;
+        q.nl = nl;
+        q.groups = (g.lines + nl - 1) / nl;
+        q.az0 = (float)g.az0; q.az_step = (float)g.az_step;
+        q.levels = s->info.max_depth + 1u;
+        q.stack_cap = 128u * q.levels;
+        const uint64_t P = p.total / p.rays_per_pose;
+        q.num_packets = P * q.groups * (g.width / 64u);
+        if (q.num_packets > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "too many rays for one launch");
+        const size_t R = (size_t)nl * 64;
+        const size_t lds_s = R * 8 + R * 12 + (size_t)q.levels * 4 + (size_t)q.stack_cap * 4 + kLeafQ * 4 + kPairQ * 8;
+        static const int sdiag = env_int("LRC_SECTOR_DIAG", 0);
+        if (sdiag) {      // work totals of this launch, printed to stderr (tools only)
+            unsigned long long* d = nullptr;
+            LRC_HIP(hipMalloc((void**)&d, kSectorDiagWords * 8));
+            LRC_HIP(hipMemsetAsync(d, 0, kSectorDiagWords * 8, st));
+            q.diag = d;
+            hipLaunchKernelGGL(sector_kernel<true>, dim3((uint32_t)q.num_packets), dim3(64), lds_s, st, q);
+            unsigned long long h[kSectorDiagWords];
+            LRC_HIP(hipStreamSynchronize(st));
+            LRC_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+            (void)hipFree(d);
+            std::fprintf(stderr, "[sector diag] packets %llu lines/packet %u: node rounds %llu, nodes %llu, leaves %llu, "
+                                 "triangles %llu, pairs %llu, pair rounds %llu, candidate rays %llu, accepted %llu\n",
+                         (unsigned long long)q.num_packets, nl, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+        } else {
+            hipLaunchKernelGGL(sector_kernel<false>, dim3((uint32_t)q.num_packets), dim3(64), lds_s, st, q);
+        }
+        return LRC_OK;
+    }
+    if (gen == 3) gen = 1;
+    if (refill > 1 && gen == 1 && !stats && p.rays_per_pose % (64u * (refill >= 4 ? 4 : 2)) == 0) {
+        const int K = refill >= 4 ? 4 : 2;        // K rays per lane with private refill
+        const uint64_t nb = (p.total + 64ull * K - 1) / (64ull * K);
+        const size_t ldsK = ((size_t)depth * 64 + (size_t)K * 64 * 2) * sizeof(int);
+        static const int rw = env_int("LRC_REFILL_W", 0);
+#define LRC_RF(KK, WW) hipLaunchKernelGGL((trace_refill_kernel<KK, WW>), dim3((uint32_t)nb), dim3(kTBlock), ldsK, st, p, depth)
+        if (K == 4) { if (rw >= 7) LRC_RF(4, 7); else LRC_RF(4, 5); }
+        else { if (rw >= 7) LRC_RF(2, 7); else LRC_RF(2, 6); }
+#undef LRC_RF
+        return LRC_OK;
+    }
+    if (stats) {
+        if (gen == 1 && qn && wide) { hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true, 2>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p); return LRC_OK; }
+        return 1;
+    }
+    const bool plain = leafw != 2 && uni && !spec && !(qn && wide);
+    if (plain || gen == 2) return 1;
+    if (gen == 1) { if (qn && wide && leafw != 2 && uni && !spec) LRC_LAB(1, 1, true, false, 2); else LRC_LAB_PICK(1); }
+    else { if (qn && wide && leafw != 2 && uni && !spec) LRC_LAB(0, 1, true, false, 2); else LRC_LAB_PICK(0); }
+#undef LRC_LAB_PICK
+#undef LRC_LAB
+    return LRC_OK;
+}
+#endif   // LRC_VARIANTS
+
+// One launch of the trace kernel over p.total rays.  gen: 0 explicit rays, 1 pose x direction table, 2 pose x scan angles,
+// 3 a grid scan (lrc_scan_grid_*: the per-ray kernel here; the packet kernel in the laboratory build).
 static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, bool stats = false) {
     p.nodes = s->d_nodes;
     p.tris = s->d_tris;
     p.slot_prim = s->d_slot_prim;
     p.slot_label = s->d_slot_label;
+    p.slot_box = s->d_slot_box;
     p.prim_plane = s->d_prim_plane;
     p.num_nodes = (uint32_t)s->info.num_nodes;
     p.nodes_q = s->d_nodes_q;
@@ -1543,101 +1669,25 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
     const uint32_t depth = s->info.max_depth < 1 ? 1 : s->info.max_depth;
     const size_t lds = (size_t)depth * kTBlock * sizeof(int);
     p.stack_cap = depth;
-    if (const char* e = std::getenv("LRC_DEBUG_FORCE_REDO")) p.force_redo = (uint32_t)std::atoi(e);
-    // measured alternative: the four-wide collapse; built and walked only under LRC_WIDE=1
-    const int wide = s->d_nodes_q4 != nullptr;
-    static const int leafw = [] { const char* e = std::getenv("LRC_LEAFW"); return e ? std::atoi(e) : 1; }();
-    static const int uni = [] { const char* e = std::getenv("LRC_UNIFORM"); return e ? std::atoi(e) : 1; }();
-    static const int spec = [] { const char* e = std::getenv("LRC_SPEC"); return e ? std::atoi(e) : 0; }();
-#define LRC_LAUNCH(G, W, U, S) \
-    hipLaunchKernelGGL((trace_kernel<G, W, U, S>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p)
-#define LRC_PICK(G)                                                                  \
-    do {                                                                             \
-        if (spec) { if (leafw == 2) LRC_LAUNCH(G, 2, true, true); else LRC_LAUNCH(G, 1, true, true); }        \
-        else if (uni) { if (leafw == 2 && qn) hipLaunchKernelGGL((trace_kernel<G, 2, true, false, false, 1>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p); \
-                        else if (leafw == 2) LRC_LAUNCH(G, 2, true, false);                                    \
-                        else if (qn && wide) hipLaunchKernelGGL((trace_kernel<G, 1, true, false, false, 2>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p); \
-                        else if (qn) hipLaunchKernelGGL((trace_kernel<G, 1, true, false, false, 1>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p); \
-                        else LRC_LAUNCH(G, 1, true, false); }  \
-        else { if (leafw == 2) LRC_LAUNCH(G, 2, false, false); else LRC_LAUNCH(G, 1, false, false); }         \
-    } while (0)
-    static const int no_sector = [] { const char* e = std::getenv("LRC_SECTOR"); return e ? std::atoi(e) == 0 : 0; }();
-    if (gen == 3 && (no_sector || stats)) gen = 1;        // A/B switch: the same scan through the per-ray kernel
-    if (gen == 3) {
-        const lrc_grid& g = *s->cur_grid;
-        SectorParams q{};
-        q.tp = p;
-        if (!s->d_slot_sphere && s->info.num_slots) {
-            LRC_HIP(hipMalloc((void**)&s->d_slot_sphere, s->info.num_slots * 16));
-            s->info.device_bytes += s->info.num_slots * 16;
-            hipLaunchKernelGGL(slot_sphere_kernel, dim3((uint32_t)((s->info.num_slots + kBlock - 1) / kBlock)), dim3(kBlock),
-                               0, st, (const float4*)s->d_tris, (uint32_t)s->info.num_slots, s->d_slot_sphere);
+#ifdef LRC_VARIANTS
+    {
+        const int rc = launch_trace_lab(s, p, gen, st, stats, nblk, lds, depth);
+        if (rc <= 0) {
+            if (rc == LRC_OK) { LRC_HIP(hipGetLastError()); s->launches += 1; s->rays += p.total; }
+            return rc;
         }
-        q.slot_sphere = s->d_slot_sphere;
-        q.H = g.lines; q.W = g.width;
-        static const int nl_env = [] { const char* e = std::getenv("LRC_SECTOR_LINES"); return e ? std::atoi(e) : 0; }();
-        uint32_t nl = nl_env > 0 ? (uint32_t)nl_env : 8u;
-        if (nl > 8u) nl = 8u;
-        if (nl > g.lines) nl = g.lines;
-        q.nl = nl;
-        q.groups = (g.lines + nl - 1) / nl;
-        q.az0 = (float)g.az0; q.az_step = (float)g.az_step;
-        q.levels = s->info.max_depth + 1u;
-        q.stack_cap = 128u * q.levels;
-        const uint64_t P = p.total / p.rays_per_pose;
-        q.num_packets = P * q.groups * (g.width / 64u);
-        if (q.num_packets > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "too many rays for one launch");
-        const size_t R = (size_t)nl * 64;
-        const size_t lds_s = R * 8 + R * 12 + (size_t)q.levels * 4 + (size_t)q.stack_cap * 4 + kLeafQ * 4 + kPairQ * 8;
-        static const int sdiag = [] { const char* e = std::getenv("LRC_SECTOR_DIAG"); return e ? std::atoi(e) : 0; }();
-        if (sdiag) {      // diagnostic build: work totals of this launch, printed to stderr (tools only)
-            unsigned long long* d = nullptr;
-            LRC_HIP(hipMalloc((void**)&d, kSectorDiagWords * 8));
-            LRC_HIP(hipMemsetAsync(d, 0, kSectorDiagWords * 8, st));
-            q.diag = d;
-            hipLaunchKernelGGL(sector_kernel<true>, dim3((uint32_t)q.num_packets), dim3(64), lds_s, st, q);
-            unsigned long long h[kSectorDiagWords];
-            LRC_HIP(hipStreamSynchronize(st));
-            LRC_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
-            (void)hipFree(d);
-            std::fprintf(stderr, "[sector diag] packets %llu lines/packet %u: node rounds %llu, nodes %llu, leaves %llu, "
-                                 "triangles %llu, pairs %llu, pair rounds %llu, candidate rays %llu, accepted %llu\n",
-                         (unsigned long long)q.num_packets, nl, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
-        } else
-        hipLaunchKernelGGL(sector_kernel<false>, dim3((uint32_t)q.num_packets), dim3(64), lds_s, st, q);
-        LRC_HIP(hipGetLastError());
-        s->launches += 1;
-        s->rays += p.total;
-        return LRC_OK;
     }
-    static const int refill = [] { const char* e = std::getenv("LRC_REFILL"); return e ? std::atoi(e) : 0; }();
-    if (refill > 1 && gen == 1 && !stats && p.rays_per_pose % (64u * (refill >= 4 ? 4 : 2)) == 0) {
-        // measured alternative: K rays per lane with private refill
-        const int K = refill >= 4 ? 4 : 2;
-        const uint64_t nb = (p.total + 64ull * K - 1) / (64ull * K);
-        const size_t ldsK = ((size_t)depth * 64 + (size_t)K * 64 * 2) * sizeof(int);
-        static const int rw = [] { const char* e = std::getenv("LRC_REFILL_W"); return e ? std::atoi(e) : 0; }();
-#define LRC_RF(KK, WW) hipLaunchKernelGGL((trace_refill_kernel<KK, WW>), dim3((uint32_t)nb), dim3(kTBlock), ldsK, st, p, depth)
-        if (K == 4) { if (rw >= 7) LRC_RF(4, 7); else LRC_RF(4, 5); }
-        else { if (rw >= 7) LRC_RF(2, 7); else LRC_RF(2, 6); }
-#undef LRC_RF
-        LRC_HIP(hipGetLastError());
-        s->launches += 1;
-        s->rays += p.total;
-        return LRC_OK;
-    }
-    if (stats) {   // diagnostic build: per-ray traversal counters (lrc_debug_scan_stats)
-        if (gen == 1 && qn && wide) hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true, 2>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
-        else if (gen == 1 && qn) hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true, 1>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
-        else if (gen == 1) hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
-        else if (gen == 0 && qn) hipLaunchKernelGGL((trace_kernel<0, 1, true, false, true, 1>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
-        else if (gen == 0) hipLaunchKernelGGL((trace_kernel<0, 1, true, false, true>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
+#endif
+    if (gen == 3) gen = 1;
+#define LRC_LAUNCH(G, S, Q) \
+    hipLaunchKernelGGL((trace_kernel<G, 1, true, false, S, Q>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p)
+    if (stats) {   // per-ray traversal counters (lrc_debug_scan_stats)
+        if (gen == 1) { if (qn) LRC_LAUNCH(1, true, 1); else LRC_LAUNCH(1, true, 0); }
+        else if (gen == 0) { if (qn) LRC_LAUNCH(0, true, 1); else LRC_LAUNCH(0, true, 0); }
         else return fail(LRC_ERR_INVALID_ARG, "traversal statistics are not available for the scan-angle generator");
-    } else if (gen == 1) LRC_PICK(1);
-    else if (gen == 2) { if (qn) hipLaunchKernelGGL((trace_kernel<2, 1, true, false, false, 1>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p);
-                         else LRC_LAUNCH(2, 1, true, false); }
-    else LRC_PICK(0);
-#undef LRC_PICK
+    } else if (gen == 1) { if (qn) LRC_LAUNCH(1, false, 1); else LRC_LAUNCH(1, false, 0); }
+    else if (gen == 2) { if (qn) LRC_LAUNCH(2, false, 1); else LRC_LAUNCH(2, false, 0); }
+    else { if (qn) LRC_LAUNCH(0, false, 1); else LRC_LAUNCH(0, false, 0); }
 #undef LRC_LAUNCH
     LRC_HIP(hipGetLastError());
     s->launches += 1;
@@ -2117,6 +2167,14 @@ int lrc_compact(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_compact
 
 // ---- scan straight to the reference's variable-length frames ----------------------------------------------------
 namespace {
+// The *_compact entry points enqueue their input copies on the null stream before anything can fail: an error return
+// must not leave such a copy in flight over staging buffers the next call reuses.
+struct SyncUnlessOk {
+    bool armed = true;
+    ~SyncUnlessOk() { if (armed) (void)hipDeviceSynchronize(); }
+    int done(int rc) { if (rc == LRC_OK) armed = false; return rc; }
+};
+
 // compacted frame arrays in HBM (context pool) and the record set they are compacted from
 struct FrameStage {
     DevBuf t, p3, sem, ins, inc, tile;                     // fixed-stride records
@@ -2175,6 +2233,16 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
     lrc_ctx* ctx = s->ctx;
     int rc = ensure_streams(ctx);
     if (rc) return rc;
+    // Every exit -- the error returns below too -- leaves the three streams idle: the caller's stage buffers go back to
+    // the context pool and its pinned destinations to Python as soon as this function returns.
+    struct Drain {
+        lrc_ctx* c;
+        ~Drain() {
+            (void)hipStreamSynchronize(c->s_compute);
+            (void)hipStreamSynchronize(c->s_copy);
+            (void)hipStreamSynchronize(c->s_stats);
+        }
+    } drain{ctx};
     if (ctx->h_counts_cap < P) {
         if (ctx->h_counts) { (void)hipHostFree(ctx->h_counts); ctx->h_counts = nullptr; ctx->h_counts_cap = 0; }
         LRC_HIP(hipHostMalloc((void**)&ctx->h_counts, (P + P / 4 + 64) * 8 * 5, hipHostMallocDefault));
@@ -2379,6 +2447,7 @@ static int scan_compact_impl(lrc_scene* s, const double* poses16, uint64_t P, co
     if (!poses16 || (!dirs3 && !d_dirs3) || !out->counts)
         return fail(LRC_ERR_INVALID_ARG, "lrc_scan_poses_compact: poses16, dirs3 or counts is NULL");
     LRC_HIP(hipSetDevice(s->ctx->device));
+    SyncUnlessOk guard;
     DevBuf dp, dd;
     int rc;
     if ((rc = dp.get(s->ctx, kPoolPoses, P * 128))) return rc;
@@ -2403,7 +2472,7 @@ static int scan_compact_impl(lrc_scene* s, const double* poses16, uint64_t P, co
     s->cur_grid = grid;
     rc = frames_finish(s, p, grid ? 3 : 1, st, P, N, out, capacity, out_total);
     s->cur_grid = nullptr;
-    return rc;
+    return guard.done(rc);
 }
 
 int lrc_scan_angles_dev(lrc_scene* s, const double* d_poses16, uint64_t P, const double* d_angles2,
@@ -2434,6 +2503,7 @@ int lrc_scan_angles_compact(lrc_scene* s, const double* poses16, uint64_t P, con
     if (!poses16 || !angles2 || !out->counts)
         return fail(LRC_ERR_INVALID_ARG, "lrc_scan_angles_compact: poses16, angles2 or counts is NULL");
     LRC_HIP(hipSetDevice(s->ctx->device));
+    SyncUnlessOk guard;
     DevBuf dp, da, dk;
     int rc;
     if ((rc = dp.get(s->ctx, kPoolPoses, P * 128)) || (rc = da.get(s->ctx, kPoolAngles, n * 16))) return rc;
@@ -2455,7 +2525,7 @@ int lrc_scan_angles_compact(lrc_scene* s, const double* poses16, uint64_t P, con
     p.total = n;
     p.has_center = 1;
     p.max_range = max_range;
-    return frames_finish(s, p, 2, st, P, N, out, capacity, out_total);
+    return guard.done(frames_finish(s, p, 2, st, P, N, out, capacity, out_total));
 }
 
 int lrc_scan_rays_compact(lrc_scene* s, const float* rays6, const uint8_t* keep, const double* centers3, uint64_t P,
@@ -2467,6 +2537,7 @@ int lrc_scan_rays_compact(lrc_scene* s, const float* rays6, const uint8_t* keep,
     if (!rays6 || !centers3 || !out->counts)
         return fail(LRC_ERR_INVALID_ARG, "lrc_scan_rays_compact: rays6, centers3 or counts is NULL");
     LRC_HIP(hipSetDevice(s->ctx->device));
+    SyncUnlessOk guard;
     DevBuf dr, dc, dk;
     int rc;
     if ((rc = dr.get(s->ctx, kPoolRays, n * 24)) || (rc = dc.get(s->ctx, kPoolCen, P * 24))) return rc;
@@ -2488,7 +2559,7 @@ int lrc_scan_rays_compact(lrc_scene* s, const float* rays6, const uint8_t* keep,
     p.total = n;
     p.has_center = 1;
     p.max_range = max_range;
-    return frames_finish(s, p, 0, st, P, N, out, capacity, out_total);
+    return guard.done(frames_finish(s, p, 0, st, P, N, out, capacity, out_total));
 }
 
 int lrc_debug_scan_stats(lrc_scene* s, const double* poses16, uint64_t P, const double* dirs3, uint64_t N,

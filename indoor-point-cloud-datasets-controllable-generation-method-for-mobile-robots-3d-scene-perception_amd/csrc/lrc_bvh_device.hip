@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256) void k_write_nodes(const TNode* nodes, uint32_
 __global__ __launch_bounds__(256) void k_tri_records(const float* verts3, const uint32_t* tris3, const uint16_t* sem,
                                                      const uint16_t* ins, const uint32_t* final_id, uint32_t T,
                                                      float4* out_tris, uint32_t* slot_prim, uint32_t* slot_label,
-                                                     float4* prim_plane) {
+                                                     float4* prim_plane, float* slot_box) {
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s >= T + 3u) return;
     float4* o = out_tris + (size_t)s * 3;
@@ -978,9 +978,21 @@ __global__ __launch_bounds__(256) void k_tri_records(const float* verts3, const 
     const float nx = __builtin_fmaf(e2[1], e1[2], -(e2[2] * e1[1]));
     const float ny = __builtin_fmaf(e2[2], e1[0], -(e2[0] * e1[2]));
     const float nz = __builtin_fmaf(e2[0], e1[1], -(e2[1] * e1[0]));
+#ifdef LRC_EDGE_TRIS
+    o[0] = make_float4(a[0], a[1], a[2], e1[0]);
+    o[1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
+    o[2] = make_float4(e2[2], nx, ny, nz);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        slot_box[(size_t)s * 6 + k] = dec(imin(imin(enc(a[k]), enc(b[k])), enc(c[k])));
+        slot_box[(size_t)s * 6 + 3 + k] = dec(imax(imax(enc(a[k]), enc(b[k])), enc(c[k])));
+    }
+#else
+    (void)slot_box;
     o[0] = make_float4(a[0], a[1], a[2], b[0]);
     o[1] = make_float4(b[1], b[2], c[0], c[1]);
     o[2] = make_float4(c[2], nx, ny, nz);
+#endif
     const uint32_t lab = (sem ? (uint32_t)sem[id] : 0u) | ((ins ? (uint32_t)ins[id] : 0u) << 16);
     slot_prim[s] = id;
     slot_label[s] = lab;
@@ -1225,7 +1237,12 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_nodes = al((size_t)nn * 64), b_q = qg.enabled ? al((size_t)nn * 32) : 0, b_n = qg.enabled ? al((size_t)nn * 64) : 0;
     const size_t b_tris = al(((size_t)T + 3) * 48), b_id = al((size_t)T * 4), b_plane = al((size_t)T * 32);
-    const size_t slab_bytes = b_nodes + b_q + b_n + b_tris + 2 * b_id + b_plane;
+#ifdef LRC_EDGE_TRIS
+    const size_t b_box = al((size_t)T * 24);
+#else
+    const size_t b_box = 0;
+#endif
+    const size_t slab_bytes = b_nodes + b_q + b_n + b_tris + 2 * b_id + b_plane + b_box;
     void* slab = nullptr;
     DB_HIP(hipMalloc(&slab, slab_bytes));
     char* sp = (char*)slab;
@@ -1236,7 +1253,8 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     out->tris = sp; sp += b_tris;
     out->slot_prim = (uint32_t*)sp; sp += b_id;
     out->slot_label = (uint32_t*)sp; sp += b_id;
-    out->prim_plane = sp;
+    out->prim_plane = sp; sp += b_plane;
+    out->slot_box = b_box ? (float*)sp : nullptr;
     auto bail = [&](int rc) { (void)hipFree(slab); *out = DeviceScene(); return rc; };
 
     const uint32_t head = std::min<uint32_t>((uint32_t)std::max(opt.bfs_nodes, 1), nn);
@@ -1252,7 +1270,7 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     hipLaunchKernelGGL(k_write_nodes, dim3(nblk), dim3(256), 0, st, (const TNode*)nodes, nn, (const uint32_t*)new_of_old,
                        (float4*)out->nodes, (uint4*)out->nodes_q, (float4*)out->nodes_n, qg, infl_part, infl_cnt, qfail, final_id);
     hipLaunchKernelGGL(k_tri_records, dim3((T + 3 + 255) / 256), dim3(256), 0, st, d_verts, d_tris, d_sem, d_ins,
-                       (const uint32_t*)final_id, T, (float4*)out->tris, out->slot_prim, out->slot_label, (float4*)out->prim_plane);
+                       (const uint32_t*)final_id, T, (float4*)out->tris, out->slot_prim, out->slot_label, (float4*)out->prim_plane, out->slot_box);
     {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { if (err) *err = std::string("device BVH build: ") + hipGetErrorString(e); return bail(LRC_ERR_HIP); }

@@ -132,6 +132,29 @@ LRC_DI bool tri_mt(V3 o, V3 d, V3 v0, V3 v1, V3 v2, V3 ng, float& t_out) {
     t_out = t;
     return true;
 }
+// tri_mt on an edge record (v0, e1 = v0 - v1, e2 = v2 - v0, Ng): the same expressions without the six subtractions
+LRC_DI bool tri_mt_e(V3 o, V3 d, V3 v0, V3 e1, V3 e2, V3 ng, float& t_out) {
+    V3 c = sub3(v0, o);
+    V3 r = cross3(c, d);
+    float den = dot3(ng, d);
+    float aden = __builtin_fabsf(den);
+    uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+    float u = xorsign(dot3(r, e2), sgn);
+    float v = xorsign(dot3(r, e1), sgn);
+    float tt = xorsign(dot3(ng, c), sgn);
+    bool ok = (den != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= aden) & (tt > 0.0f);
+    if (!ok) return false;
+    float t = tt / aden;
+    if (!(t < __builtin_inff())) return false;
+    t_out = t;
+    return true;
+}
+// the box clause on a stored vertex box
+LRC_DI bool box_clause(const RaySlab& s, float lox, float loy, float loz, float hix, float hiy, float hiz, float t) {
+    float tn, tf;
+    slab_interval(s, lox, loy, loz, hix, hiy, hiz, tn, tf);
+    return (tn <= t) & (t <= tf);
+}
 LRC_DI bool tri_clause(const RaySlab& s, V3 v0, V3 v1, V3 v2, float t) {
     float lox = min2(min2(v0.x, v1.x), v2.x), hix = max2(max2(v0.x, v1.x), v2.x);
     float loy = min2(min2(v0.y, v1.y), v2.y), hiy = max2(max2(v0.y, v1.y), v2.y);

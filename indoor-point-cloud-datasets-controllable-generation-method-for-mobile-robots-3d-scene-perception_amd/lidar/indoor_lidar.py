@@ -121,13 +121,12 @@ class DualAxisLidar:
         assert isinstance(self.intrinsics, DualAxisLidarIntrinsics)
         _check_pose(self.pose)
 
-    def scan_angles(self, num_points=None):
-        """Noisy (phi, theta) per ray, float64 (N,), and the dropout keep mask.  Consumes the RNG."""
+    def scan_pattern(self, num_points=None):
+        """Noise-free (phi, theta) of the scan, float64 (N,) each: a function of the intrinsics alone, computed once per
+        intrinsics object and scan size (callers must not modify the arrays)."""
         k = self.intrinsics
-        rnd = np.random if self.rng is None else self.rng
         if num_points is None:
             num_points = int(k.point_rate * k.scan_duration)
-        # the noise-free pattern depends on the intrinsics alone: computed once per intrinsics object and scan size
         key = (num_points, k.num_vertical_lines, tuple(k.theta_range), k.swing_amplitude, k.swing_frequency)
         cached = getattr(k, "_scan_pattern", None)
         if cached is None or cached[0] != key:
@@ -144,7 +143,14 @@ class DualAxisLidar:
                 k._scan_pattern = cached
             except Exception:          # frozen / slotted intrinsics: no cache
                 pass
-        phi, theta = cached[1].copy(), cached[2].copy()
+        return cached[1], cached[2]
+
+    def scan_angles(self, num_points=None):
+        """Noisy (phi, theta) per ray, float64 (N,), and the dropout keep mask.  Consumes the RNG."""
+        k = self.intrinsics
+        rnd = np.random if self.rng is None else self.rng
+        phi, theta = self.scan_pattern(num_points)
+        phi, theta = phi.copy(), theta.copy()
         n = phi.size
         if k.angle_noise_std > 0:
             z = rnd.normal(0, k.angle_noise_std, size=2 * n).reshape(n, 2)
@@ -153,6 +159,19 @@ class DualAxisLidar:
         keep = None
         if k.dropout_probability > 0:
             keep = rnd.random(n) > k.dropout_probability
+        return phi, theta, keep
+
+    def scan_angles_from_draws(self, z, u, num_points=None):
+        """The same from draws made elsewhere (lidarcast.nprandom.scan_draws: a whole trajectory's draws of the seeded
+        stream in one native call): z = the 2N normals of this pose (or None), u = its N uniforms (or None)."""
+        k = self.intrinsics
+        phi, theta = self.scan_pattern(num_points)
+        phi, theta = phi.copy(), theta.copy()
+        if z is not None:
+            z = z.reshape(phi.size, 2)
+            phi += z[:, 0]
+            theta += z[:, 1]
+        keep = None if u is None else u > k.dropout_probability
         return phi, theta, keep
 
     def all_rays_and_mask(self, num_points: int = None, out: np.ndarray = None):

@@ -34,6 +34,7 @@ SYMBOLS = (
     "lrc_nn_create", "lrc_nn_destroy", "lrc_nn_query", "lrc_nn_query_dev",
     "lrc_min_distances", "lrc_rbf_kernel_sum",
     "lrc_occ_create", "lrc_occ_destroy", "lrc_occ_query",
+    "lrc_rng_scan_draws",
 )
 
 
@@ -72,6 +73,10 @@ class LrcFrames(C.Structure):
                 ("incident_deg", C.c_void_p), ("index", C.c_void_p), ("xyzl", C.c_void_p),
                 ("range_origin", C.c_void_p), ("range_origin_mean", C.c_void_p), ("range_origin_std", C.c_void_p),
                 ("incident_mean", C.c_void_p), ("incident_std", C.c_void_p)]
+
+
+class LrcMt19937State(C.Structure):
+    _fields_ = [("key", C.c_uint32 * 624), ("pos", C.c_int32), ("has_gauss", C.c_int32), ("gauss", C.c_double)]
 
 
 class LrcGrid(C.Structure):
@@ -146,6 +151,7 @@ def load():
         "lrc_cloud_from_prims_dev": [vp, vp, u64, vp, u64, vp, vp, u64, u64, vp, vp, vp],
         "lrc_compact": [vp, u64, u64, C.POINTER(LrcCompactIO), C.POINTER(u64)],
         "lrc_compact_dev": [vp, u64, u64, C.POINTER(LrcCompactIO), vp],
+        "lrc_rng_scan_draws": [C.POINTER(LrcMt19937State), u64, u64, u64, dbl, dbl, vp, vp, i32],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)

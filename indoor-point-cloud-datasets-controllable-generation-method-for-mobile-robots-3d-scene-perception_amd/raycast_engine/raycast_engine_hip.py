@@ -67,6 +67,55 @@ def _ray_pool():
     return _RAY_POOL
 
 
+def dual_axis_rays_batch(lidars, rays, keep):
+    """All rays of all poses of a dual-axis trajectory BEFORE the dropout, into ``rays`` (P, n, 6) float32, and the dropout
+    masks into ``keep`` (P, n) uint8/bool (pre-set to 1) -- ``rays[i][keep[i]]`` is ``lidars[i].get_rays()`` and the
+    generator is left where P calls of get_rays() would leave it (reference: lidar/indoor_lidar.py:257-296).  Host only."""
+    k0 = lidars[0].intrinsics
+    P, n = len(lidars), rays.shape[1]
+    # the random draws are sequential by definition of the seeded stream (pose after pose, angles then dropout);
+    # the trigonometry and rotation of a pose depend on nothing else and run on a thread pool beside the next
+    # poses' draws (numpy releases the GIL in both); at most 48 poses' angle arrays are alive
+    import collections
+    from lidarcast import nprandom
+    pool, pending = _ray_pool(), collections.deque()
+    rng = lidars[0].rng
+    same = all(l.intrinsics is k0 or l.intrinsics == k0 for l in lidars) and all(l.rng is rng for l in lidars)
+    if same and nprandom.supported(rng) and hasattr(lidars[0], "scan_angles_from_draws"):
+        # numpy's legacy stream restated natively (csrc/lrc_nprandom.cpp): the draws of a run of poses in ONE call
+        # -- the same doubles, the same generator state afterwards -- while the pool turns the previous run's
+        # angles into rays
+        nn = 2 * n if k0.angle_noise_std > 0 else 0
+        nu = n if k0.dropout_probability > 0 else 0
+
+        def one(l, z, u, out, km):
+            phi, theta, k = l.scan_angles_from_draws(z, u)
+            if k is not None:
+                km[:] = k
+            l.rays_from_angles(phi, theta, out)
+        run = 16
+        for a in range(0, P, run):
+            b = min(P, a + run)
+            z, u = nprandom.scan_draws(b - a, nn, nu, 0.0, k0.angle_noise_std, rng=rng)
+            for i in range(a, b):
+                pending.append(pool.submit(one, lidars[i], z[i - a] if nn else None, u[i - a] if nu else None,
+                                           rays[i], keep[i]))
+            while len(pending) > 48:
+                pending.popleft().result()
+    else:
+        for i, l in enumerate(lidars):
+            phi, theta, k = l.scan_angles()
+            if phi.size != n:
+                raise ValueError("dual-axis poses must share one ray count")
+            if k is not None:
+                keep[i] = k
+            pending.append(pool.submit(l.rays_from_angles, phi, theta, rays[i]))
+            while len(pending) > 48:
+                pending.popleft().result()
+    for f in pending:
+        f.result()
+
+
 class RaycastEngineHIP(RaycastEngineBase):
     """HIP (gfx950) engine.  ``RaycastEngineGPU`` is this class."""
 
@@ -287,22 +336,7 @@ class RaycastEngineHIP(RaycastEngineBase):
         rays = self.ctx.pinned.take(P * n * 24)[:P * n * 24].view(np.float32).reshape(P, n, 6)
         keep = self.ctx.pinned.take(P * n)[:P * n].reshape(P, n)
         keep[:] = 1
-        # the random draws are sequential by definition of the seeded stream (pose after pose, angles then dropout);
-        # the trigonometry and rotation of a pose depend on nothing else and run on a thread pool beside the next
-        # poses' draws (numpy releases the GIL in both); at most 48 poses' angle arrays are alive
-        import collections
-        pool, pending = _ray_pool(), collections.deque()
-        for i, l in enumerate(lidars):
-            phi, theta, k = l.scan_angles()
-            if phi.size != n:
-                raise ValueError("dual-axis poses must share one ray count")
-            if k is not None:
-                keep[i] = k
-            pending.append(pool.submit(l.rays_from_angles, phi, theta, rays[i]))
-            while len(pending) > 48:
-                pending.popleft().result()
-        for f in pending:
-            f.result()
+        dual_axis_rays_batch(lidars, rays, keep)
         centers = np.stack([np.asarray(l.pose, dtype=np.float64)[:3, 3] for l in lidars])
         return self.scene_for(mesh).scan_rays_compact(rays, keep, centers, k0.max_range, want=want)
 

@@ -312,7 +312,9 @@ def run_scene_batch(scenes, trajectories, sensor=None, config: Optional[Dict[str
     Inside a torch.distributed job the scenes are dealt round-robin to the ranks (each scene is one rank's work, its
     trajectory is not sharded again) and the per-scene summaries are gathered; ``sim_scene`` objects stay on the
     rank that produced them.  Returns {"scenes": {name: {...}}, "failed": [...], "skipped": [...], "total_rays",
-    "seconds", "rays_per_s"} with seconds = the scan stages only (scene builds and file writing excluded)."""
+    "seconds", "rays_per_s", "build_seconds", "seconds_including_build", "rays_per_s_including_build"}: ``seconds`` = the
+    scan stages only, ``build_seconds`` = the scene builds (mesh -> BVH resident in HBM, which the reference pays per
+    POSE, raycast_engine_cpu.py:46-47, and this engine once per mesh, on the GPU); file writing is in neither."""
     from lidarcast.distributed import active_group
     dist, group = active_group(process_group)
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist is not None else (0, 1)
@@ -340,14 +342,15 @@ def run_scene_batch(scenes, trajectories, sensor=None, config: Optional[Dict[str
                                       timestamp=float(k)) for k, m in enumerate(traj.reshape(-1, 4, 4))]
             else:
                 waypoints = list(traj)
-            sim.raycast_engine.scene_for(sim.scene.room_mesh)        # scene build: outside the scan timing
+            tb = time.perf_counter()
+            sim.raycast_engine.scene_for(sim.scene.room_mesh)        # scene build: timed on its own
             t0 = time.perf_counter()
             sim_scene = sim.run_simulation(waypoints, process_group=_NO_GROUP)
             dt = time.perf_counter() - t0
             if out_dir is not None:
                 sim.save_results(sim_scene, out_dir, waypoints)
             done[name] = {"sim_scene": sim_scene, "frames": len(sim_scene.frames), "rays": len(waypoints) * rays_per_pose,
-                          "points": int(sim_scene.get_total_points()), "seconds": dt}
+                          "points": int(sim_scene.get_total_points()), "seconds": dt, "build_seconds": t0 - tb}
         except Exception as e:                                       # noqa: BLE001 - the reference collects and goes on
             failed.append((name, str(e)))
     if dist is not None:
@@ -360,9 +363,13 @@ def run_scene_batch(scenes, trajectories, sensor=None, config: Optional[Dict[str
                 failed += fl
                 skipped += sk
         seconds = max(sum(v["seconds"] for v in part[0].values()) for part in parts)    # ranks work side by side
+        with_build = max(sum(v["seconds"] + v["build_seconds"] for v in part[0].values()) for part in parts)
     else:
         seconds = sum(v["seconds"] for v in done.values())
+        with_build = sum(v["seconds"] + v["build_seconds"] for v in done.values())
     total_rays = sum(v["rays"] for v in done.values())
     order = [n for n, _ in scenes]
     return {"scenes": {n: done[n] for n in order if n in done}, "failed": failed, "skipped": skipped, "ranks": world,
-            "total_rays": int(total_rays), "seconds": seconds, "rays_per_s": total_rays / seconds if seconds > 0 else 0.0}
+            "total_rays": int(total_rays), "seconds": seconds, "rays_per_s": total_rays / seconds if seconds > 0 else 0.0,
+            "build_seconds": with_build - seconds, "seconds_including_build": with_build,
+            "rays_per_s_including_build": total_rays / with_build if with_build > 0 else 0.0}

@@ -20,7 +20,7 @@ def pytest_configure(config):
     # broken extension can never turn into skipped or quietly passing tests.
     import __graft_entry__ as entry
     deps = [os.path.join(entry.CSRC, f) for f in os.listdir(entry.CSRC)] + [os.path.join(REPO, "include", "lidarcast.h")]
-    if entry._stale(entry.LIB, deps):
+    if entry._stale(entry.LIB, deps) or entry._stale(entry.LAB_LIB, deps):
         entry.build()
 
 

@@ -1,0 +1,106 @@
+"""CPU: the native restatement of numpy's legacy seeded stream (csrc/lrc_nprandom.cpp) against numpy itself -- the
+doubles, their order and the generator state afterwards, for the draw pattern of the reference's dual-axis generator
+(reference: lidar/indoor_lidar.py:257-296: per pose 2N normals, then N uniforms) and around every edge of the
+restatement: block boundaries of the MT19937 state, a cached normal left by an earlier odd draw, odd counts, zero
+counts, the global stream and RandomState objects."""
+import numpy as np
+import pytest
+
+
+def _numpy_draws(rs, P, nn, nu, loc, scale):
+    z = np.empty((P, nn))
+    u = np.empty((P, nu))
+    for p in range(P):
+        z[p] = rs.normal(loc, scale, nn)
+        u[p] = rs.random_sample(nu)
+    return z, u
+
+
+def _same_state(a, b):
+    return a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+
+
+@pytest.mark.parametrize("seed,P,nn,nu,pre", [
+    (0, 3, 2000, 1000, 0),         # the sensor's pattern, small
+    (1, 5, 128, 64, 0),
+    (12345, 2, 1, 0, 0),           # odd counts leave a cached normal behind
+    (7, 4, 3, 5, 1),               # ... and start from one (pre = normals drawn before)
+    (7, 3, 0, 17, 1),              # no normals: the cached value survives the call
+    (3, 2, 624, 312, 0),           # exactly block-sized draws
+    (3, 6, 311, 1, 623),           # consumption points crossing block ends at every phase
+    (99, 1, 0, 0, 0),
+    (5, 2, 50001, 25001, 0),       # odd and large
+])
+@pytest.mark.parametrize("threads", [1, 3])
+def test_matches_numpy(seed, P, nn, nu, pre, threads):
+    from lidarcast import nprandom
+    ref, mine = np.random.RandomState(seed), np.random.RandomState(seed)
+    if pre:
+        ref.normal(size=pre); mine.normal(size=pre)
+        ref.random_sample(3); mine.random_sample(3)
+    zr, ur = _numpy_draws(ref, P, nn, nu, 0.25, 1e-3)
+    zm, um = nprandom.scan_draws(P, nn, nu, 0.25, 1e-3, rng=mine, threads=threads)
+    assert np.array_equal(zr.view(np.uint64), zm.view(np.uint64))
+    assert np.array_equal(ur.view(np.uint64), um.view(np.uint64))
+    assert _same_state(ref.get_state(), mine.get_state())
+    # and the streams stay together afterwards
+    assert np.array_equal(ref.normal(size=5), mine.normal(size=5)) and ref.randint(1 << 30) == mine.randint(1 << 30)
+
+
+def test_global_stream_and_sensor_sized_draw():
+    """np.random itself (what the reference uses), one BLK2GO pose: 128 000 normals of sigma 1e-3, 64 000 uniforms."""
+    from lidarcast import nprandom
+    np.random.seed(0)
+    z_ref = np.random.normal(0, 1e-3, size=128000)
+    u_ref = np.random.random(64000)
+    z2_ref = np.random.normal(0, 1e-3, size=128000)
+    after = np.random.get_state()
+    np.random.seed(0)
+    z, u = nprandom.scan_draws(2, 128000, 64000, 0.0, 1e-3)
+    assert np.array_equal(z[0].view(np.uint64), z_ref.view(np.uint64))
+    assert np.array_equal(u[0].view(np.uint64), u_ref.view(np.uint64))
+    assert np.array_equal(z[1].view(np.uint64), z2_ref.view(np.uint64))
+    np.random.random(64000)
+    # (the native call drew the second pose's uniforms too: re-seed and compare states pose for pose)
+    np.random.seed(0)
+    nprandom.scan_draws(1, 128000, 64000, 0.0, 1e-3)
+    nprandom.scan_draws(1, 128000, 0, 0.0, 1e-3)
+    assert _same_state(np.random.get_state(), after)
+
+
+def test_only_the_legacy_stream_is_accepted():
+    from lidarcast import nprandom
+    assert nprandom.supported(None) and nprandom.supported(np.random.RandomState(3))
+    assert not nprandom.supported(np.random.default_rng(3))
+    with pytest.raises(TypeError):
+        nprandom.scan_draws(1, 2, 2, rng=np.random.default_rng(3))
+
+
+@pytest.mark.parametrize("seed", [0, 12345])
+def test_trajectory_rays_match_per_pose_generator(seed):
+    """The batched host generator of the dual-axis sensor (native draws for runs of poses + thread pool) against
+    ``get_rays()`` called pose after pose on the same seed: identical rays, identical masks, identical generator state
+    afterwards -- for the global stream and for a private RandomState."""
+    import dataclasses
+    from lidar import DualAxisLidar, DualAxisLidarIntrinsics
+    from raycast_engine.raycast_engine_hip import dual_axis_rays_batch
+    from helpers import pose
+    k = dataclasses.replace(DualAxisLidarIntrinsics.create_blk2go_dual_axis(), point_rate=64000.0)   # 6 400 rays per pose
+    poses = [pose(1.0 + 0.1 * i, 2.0, 1.0, yaw=0.3 * i) for i in range(37)]
+    n = k.num_vertical_lines * (int(k.point_rate * k.scan_duration) // k.num_vertical_lines)
+    for private in (False, True):
+        rs = np.random.RandomState(seed) if private else None
+        np.random.seed(seed)
+        ref = [DualAxisLidar(k, m, rng=rs).get_rays() for m in poses]
+        state_ref = rs.get_state() if private else np.random.get_state()
+        rs = np.random.RandomState(seed) if private else None
+        np.random.seed(seed)
+        lidars = [DualAxisLidar(k, m, rng=rs) for m in poses]
+        rays = np.empty((len(poses), n, 6), dtype=np.float32)
+        keep = np.ones((len(poses), n), dtype=np.uint8)
+        dual_axis_rays_batch(lidars, rays, keep)
+        state = rs.get_state() if private else np.random.get_state()
+        assert _same_state(state_ref, state)
+        for i in range(len(poses)):
+            got = rays[i][keep[i].astype(bool)]
+            assert got.shape == ref[i].shape and np.array_equal(got.view(np.uint32), ref[i].view(np.uint32)), i

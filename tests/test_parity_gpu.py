@@ -956,30 +956,148 @@ def test_export_labels_from_annotated_cloud(tmp_path, engine):
 
 
 def test_kernel_variants_are_bit_identical():
-    """Traversal order / fetch strategy / leaf size must not change a single output byte:
-    the scalar-fetch, leaf-pair, speculative-postponement, small-leaf and node-image (float32 / quantised / four-wide)
-    variants against the default, and the quantised path with every third / every ray sent through its redo path (the
+    """Traversal order / fetch strategy / leaf size / builder must not change a single output byte.
+    The product library with the scene built on the device (default) and on the host, with smaller leaves, with every
+    split forced through the median fallback, on float32 nodes and on forced quantised images; then the laboratory build
+    (-DLRC_VARIANTS, liblidarcast_lab.so through LRC_LIB): scalar fetch off, leaf pairs, speculative postponement, private
+    refill, four-wide nodes, and the quantised path with every third / every ray sent through its redo route (the
     route a ray takes when its closest candidate fails the box clause, which no input so far has made happen)."""
     import subprocess
     import sys
+    import __graft_entry__ as entry
     from conftest import REPO
     tool = os.path.join(REPO, "tools", "variant_digest.py")
+    assert os.path.exists(entry.LAB_LIB)
+    lab = {"LRC_LIB": entry.LAB_LIB}
+    variants = {"default": {}, "host_builder": {"LRC_DEVICE_BUILD": "0"},
+                "leaves_of_2": {"LRC_MAX_LEAF": "2"}, "leaves_of_1": {"LRC_MAX_LEAF": "1"},
+                "leaves_of_1_host_builder": {"LRC_MAX_LEAF": "1", "LRC_DEVICE_BUILD": "0"},
+                "median_splits_only": {"LRC_BUILD_MEDIAN_ONLY": "1"}, "no_depth_slack": {"LRC_DEPTH_SLACK": "0"},
+                "float32_nodes": {"LRC_QNODES": "0"}, "quantised_nodes_forced": {"LRC_QNODES": "2"},
+                "lab_default": lab, "no_scalar_fetch": dict(lab, LRC_UNIFORM="0"), "leaf_pairs": dict(lab, LRC_LEAFW="2"),
+                "speculative": dict(lab, LRC_SPEC="1"), "refill_2": dict(lab, LRC_REFILL="2"),
+                "refill_4": dict(lab, LRC_REFILL="4"), "refill_2_w7": dict(lab, LRC_REFILL="2", LRC_REFILL_W="7"),
+                "quantised_leaf_pairs": dict(lab, LRC_QNODES="2", LRC_LEAFW="2"),
+                "four_wide_nodes": dict(lab, LRC_QNODES="2", LRC_WIDE="1"),
+                "every_third_ray_redone": dict(lab, LRC_QNODES="2", LRC_DEBUG_FORCE_REDO="3"),
+                "every_ray_redone": dict(lab, LRC_QNODES="2", LRC_DEBUG_FORCE_REDO="1")}
     digests = {}
-    for name, env in {"default": {}, "no_scalar_fetch": {"LRC_UNIFORM": "0"}, "leaf_pairs": {"LRC_LEAFW": "2"},
-                      "speculative": {"LRC_SPEC": "1"}, "leaves_of_2": {"LRC_MAX_LEAF": "2"},
-                      "leaves_of_1": {"LRC_MAX_LEAF": "1"}, "refill_2": {"LRC_REFILL": "2"},
-                      "refill_4": {"LRC_REFILL": "4"}, "refill_2_w7": {"LRC_REFILL": "2", "LRC_REFILL_W": "7"},
-                      "float32_nodes": {"LRC_QNODES": "0"}, "quantised_nodes_forced": {"LRC_QNODES": "2"},
-                      "quantised_leaf_pairs": {"LRC_QNODES": "2", "LRC_LEAFW": "2"},
-                      "four_wide_nodes": {"LRC_QNODES": "2", "LRC_WIDE": "1"},
-                      "every_third_ray_redone": {"LRC_QNODES": "2", "LRC_DEBUG_FORCE_REDO": "3"},
-                      "every_ray_redone": {"LRC_QNODES": "2", "LRC_DEBUG_FORCE_REDO": "1"}}.items():
+    for name, env in variants.items():
         e = dict(os.environ)
         e.update(env)
         r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=300, env=e, check=True)
         digests[name] = r.stdout.strip().splitlines()[-1]
     assert len(set(digests.values())) == 1, digests
     assert int(digests["default"].split()[1]) > 30000 and int(digests["default"].split()[2]) > 1000
+
+
+def _build_both(ctx, mesh, **env):
+    """The same mesh through the host builder and the device builder (LRC_* build knobs from env)."""
+    import lidarcast
+    scenes = []
+    keys = list(env) + ["LRC_DEVICE_BUILD"]
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        for k, v in env.items():
+            os.environ[k] = str(v)
+        for dev in ("0", "1"):
+            os.environ["LRC_DEVICE_BUILD"] = dev
+            scenes.append(lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, getattr(mesh, "triangle_sem", None),
+                                          getattr(mesh, "triangle_ins", None)))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return scenes
+
+
+def _assert_same_scene(host, dev, what):
+    ih, idv = host.info, dev.info
+    assert ih["device_build"] == 0 and idv["device_build"] == 1, what
+    for k in ("num_nodes", "num_leaves", "num_slots", "max_depth", "max_leaf_size", "bounds_lo", "bounds_hi",
+              "quantised_nodes"):
+        assert ih[k] == idv[k], (what, k, ih[k], idv[k])
+    assert abs(ih["leaf_inflation"] - idv["leaf_inflation"]) < 1e-6, what
+    for a in ("nodes", "tris", "slot_prim", "slot_label", "prim_plane", "nodes_q", "nodes_n"):
+        x, y = host.export_array(a), dev.export_array(a)
+        assert x.shape == y.shape and np.array_equal(x, y), f"{what}: array {a} differs"
+
+
+def test_device_build_equals_host_build(ctx):
+    """The scene build on the GPU (csrc/lrc_bvh_device.hip) against the host builder (csrc/bvh_build.cpp): the same tree
+    and the same bytes in every array the trace kernels read -- nodes, triangle records, ids, labels, plane table and both
+    quantised images -- for rooms and soups around every size-class boundary of the device builder (one wave <= 64, one
+    workgroup <= 1024, chunked above), all leaf sizes, layout heads that cut a level in the middle, depth caps that
+    force median splits near the root, the median-only hook (the radix-sort path of big nodes), snapped coordinates with
+    signed zeros, and a mesh no SAH plane can split."""
+    from lidarcast import synth
+    from lidarcast.synth import TriangleMesh
+    room = synth.make_room(size=(3.0, 2.5, 2.0), num_boxes=3, seed=9, cell=0.05)
+    _assert_same_scene(*_build_both(ctx, room), "room")
+    for ml in (1, 2, 3):
+        _assert_same_scene(*_build_both(ctx, room, LRC_MAX_LEAF=ml), f"room max_leaf={ml}")
+    for bfs in (1, 2, 7, 100, 10 ** 6):
+        _assert_same_scene(*_build_both(ctx, room, LRC_BFS_NODES=bfs), f"room bfs_nodes={bfs}")
+    for sl in (0, 1, 5, -1):
+        _assert_same_scene(*_build_both(ctx, room, LRC_DEPTH_SLACK=sl), f"room depth_slack={sl}")
+    _assert_same_scene(*_build_both(ctx, room, LRC_BUILD_MEDIAN_ONLY=1), "room, median splits only")
+    rng = np.random.default_rng(3)
+    for nt in (5, 6, 9, 64, 65, 66, 200, 1024, 1025, 1030, 3000, 20000):
+        v, f = random_soup(nt, seed=nt)
+        m = TriangleMesh(v, f)
+        _assert_same_scene(*_build_both(ctx, m), f"soup {nt}")
+        _assert_same_scene(*_build_both(ctx, m, LRC_BUILD_MEDIAN_ONLY=1), f"soup {nt}, median splits only")
+    nt = 5000
+    v = np.round(rng.uniform(-2, 2, (nt, 3, 3)) * 2) / 2
+    v[v == 0] = rng.choice([0.0, -0.0], size=int((v == 0).sum()))
+    snapped = TriangleMesh(v.reshape(-1, 3), np.arange(3 * nt).reshape(-1, 3))
+    _assert_same_scene(*_build_both(ctx, snapped), "snapped soup")
+    same = TriangleMesh(np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float64), (3000, 1)),
+                        np.arange(9000).reshape(-1, 3))
+    _assert_same_scene(*_build_both(ctx, same), "3000 coincident triangles")
+    # errors come back as the host builder reports them
+    import lidarcast
+    with pytest.raises(ValueError, match="out of range"):
+        lidarcast.Scene(ctx, room.vertices, np.concatenate([room.triangles, [[0, 1, len(room.vertices)]]]))
+    bad = np.array(room.vertices, dtype=np.float64)
+    bad[17, 1] = np.inf
+    with pytest.raises(ValueError, match="not finite"):
+        lidarcast.Scene(ctx, bad, room.triangles)
+
+
+def test_device_build_full_size_and_device_resident_mesh(ctx):
+    """BASELINE-size scenes: device build == host build byte for byte; a mesh handed over in HBM (lrc_scene_create_dev)
+    gives the same scene again; the build stays inside its time budget (T = 605 k resident in <= 10 ms)."""
+    import time
+    import torch
+    import lidarcast
+    from lidarcast import synth
+    for name in ("synth_A6_office2", "synth_rough_A6"):
+        mesh = synth.make_scene(name)
+        host, dev = _build_both(ctx, mesh)
+        _assert_same_scene(host, dev, name)
+        d = torch.device("cuda", 0)
+        v = torch.from_numpy(np.ascontiguousarray(mesh.vertices, dtype=np.float32)).to(d)
+        f = torch.from_numpy(np.ascontiguousarray(mesh.triangles, dtype=np.int32)).to(d)
+        sem = torch.from_numpy(mesh.triangle_sem.astype(np.int16)).to(d)
+        ins = torch.from_numpy(mesh.triangle_ins.astype(np.int16)).to(d)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        resident = lidarcast.Scene.from_device(ctx, v, f, sem, ins)
+        ms_resident = (time.perf_counter() - t0) * 1e3
+        for a in ("nodes", "tris", "slot_prim", "slot_label", "prim_plane", "nodes_q", "nodes_n"):
+            assert np.array_equal(resident.export_array(a), host.export_array(a)), (name, a)
+        t0 = time.perf_counter()
+        again = lidarcast.Scene(ctx, mesh.vertices.astype(np.float32), mesh.triangles.astype(np.uint32),
+                                mesh.triangle_sem, mesh.triangle_ins)
+        ms_host_mesh = (time.perf_counter() - t0) * 1e3
+        info = again.info
+        print(f"{name}: T={info['num_triangles']} host builder {host.info['build_ms']:.1f} ms | device builder: mesh in "
+              f"host memory {ms_host_mesh:.2f} ms (transfer {info['upload_ms']:.2f} + build {info['build_ms']:.2f}), "
+              f"mesh in HBM {ms_resident:.2f} ms")
+        assert ms_host_mesh < 10.0 and ms_resident < 10.0, (ms_host_mesh, ms_resident)
 
 
 def test_export_labels_from_annotation_files(tmp_path, engine):

@@ -69,6 +69,9 @@ enum PoolSlot { kPoolRays = 0, kPoolT, kPoolPrim, kPoolNormal, kPoolPoint, kPool
                 kPoolAngles, kPoolKeep, kPoolTile, kPoolCounts, kPoolOutPoint, kPoolOutSem, kPoolOutIns, kPoolOutInc,
                 kPoolOutIdx, kPoolOutXyzl, kPoolOutRange, kPoolStats, kPoolFrameStats, kPoolSlots };
 
+#ifndef LRC_LEAFW2_WAVES
+#define LRC_LEAFW2_WAVES 0   // A/B builds: 8 = hold the leaf-pair kernel (laboratory, LRC_LEAFW=2) to 8 waves per SIMD
+#endif
 #ifndef LRC_REBUILD_R
 #define LRC_REBUILD_R 2      // tiles (of 64 entries) one wave of the cloud rebuild handles (1, 2, 4, 8 measured equal)
 #endif
@@ -377,7 +380,7 @@ template <int I> struct IntTag { static constexpr int value = I; };
 //     four-wide collapse (64-byte nodes, half the steps); a wave with a ray outside the bound the quantisation margin is
 //     proven for walks the float32 world-space nodes instead
 template <int GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false, int QN = 0>
-__global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW == 1) ? 8 : 1) void trace_kernel(const TraceParams p) {
+__global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && (LEAFW == 1 || LRC_LEAFW2_WAVES == 8)) ? 8 : 1) void trace_kernel(const TraceParams p) {
     extern __shared__ int s_stack[];   // [stack depth][kTBlock]: one column per lane, conflict free
     const uint32_t tid = threadIdx.x;
     const uint64_t gid = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * kTBlock + tid;
@@ -600,10 +603,8 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
                                 if (STATS) { if (!hit) st_pad += 1u; }
                             }
                         }
-                        if (false) {
 #else
                         if (Q) {
-#endif
                             // Candidates are ranked by the Moeller-Trumbore conditions alone; the definition's box
                             // clause (world coordinates) is tested once, after the traversal, on the closest candidate.
                             // If that candidate passes, it is the definition's closest hit: every triangle passing both
@@ -613,6 +614,7 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && LEAFW ==
                         } else {
                             hit = tri_hit<STATS>(o, d, sl, v0, v1, v2, ng, t, &st_pad);
                         }
+#endif
                         if (hit) {
                             if (t < tbest) {
                                 tbest = t; best_slot = slot; best_prim = 0xFFFFFFFFu;
@@ -1180,6 +1182,20 @@ __global__ __launch_bounds__(kBlock) void slot_sphere_kernel(const float4* __res
 
 #endif   // LRC_VARIANTS
 
+// Per caller's triangle ROW: (v0, label bits), (Ng, 0) -- all a known hit needs to give t again.  Read by the multi-GPU
+// cloud rebuild only (lrc_cloud_from_prims_dev), so it is built from the slot arrays the first time that is called.
+__global__ __launch_bounds__(kBlock) void prim_plane_kernel(const float4* __restrict__ tris, const uint32_t* __restrict__ slot_prim,
+                                                            const uint32_t* __restrict__ slot_label, uint32_t num_slots,
+                                                            uint32_t num_prims, float4* __restrict__ plane) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= num_slots) return;
+    const uint32_t row = slot_prim[k];
+    if (row >= num_prims) return;
+    const float4 a = tris[(size_t)k * 3], c = tris[(size_t)k * 3 + 2];
+    plane[(size_t)row * 2] = make_float4(a.x, a.y, a.z, __uint_as_float(slot_label[k]));
+    plane[(size_t)row * 2 + 1] = make_float4(c.y, c.z, c.w, 0.0f);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1257,10 +1273,10 @@ int lrc_scene_destroy(lrc_scene* s) {
         if (s->d_slot_prim) (void)hipFree(s->d_slot_prim);
         if (s->d_slot_label) (void)hipFree(s->d_slot_label);
         if (s->d_slot_box) (void)hipFree(s->d_slot_box);
-        if (s->d_prim_plane) (void)hipFree(s->d_prim_plane);
         if (s->d_nodes_q) (void)hipFree(s->d_nodes_q);
         if (s->d_nodes_n) (void)hipFree(s->d_nodes_n);
     }
+    if (s->d_prim_plane) (void)hipFree(s->d_prim_plane);
     if (s->d_slot_sphere) (void)hipFree(s->d_slot_sphere);
     if (s->d_nodes_q4) (void)hipFree(s->d_nodes_q4);
     if (s->d_nodes_n4) (void)hipFree(s->d_nodes_n4);
@@ -1314,7 +1330,6 @@ int scene_create_device(lrc_ctx* ctx, const float* verts3, uint64_t V, const uin
     s->d_slot_prim = d.slot_prim;
     s->d_slot_label = d.slot_label;
     s->d_slot_box = d.slot_box;
-    s->d_prim_plane = (float4*)d.prim_plane;
     s->d_nodes_q = (uint4*)d.nodes_q;
     s->d_nodes_n = (float4*)d.nodes_n;
     for (int a = 0; a < 3; ++a) { s->qbase[a] = d.qbase[a]; s->qW[a] = d.qW[a]; s->qinvW[a] = d.qinvW[a]; }
@@ -1387,18 +1402,8 @@ int scene_create_host(lrc_ctx* ctx, const float* verts3, uint64_t V, const uint3
         in.device_bytes += bytes;
         return LRC_OK;
     };
-    std::vector<float> prim_plane(T * 8, 0.0f);
-    for (size_t k = 0; k < h.slot_prim.size(); ++k) {
-        if (h.slot_prim[k] >= T) continue;
-        const float* r = h.tri_rec.data() + k * 12;       // v0 v1 v2 Ng
-        float* q = prim_plane.data() + (size_t)h.slot_prim[k] * 8;
-        q[0] = r[0]; q[1] = r[1]; q[2] = r[2];
-        std::memcpy(&q[3], &h.slot_label[k], 4);
-        q[4] = r[9]; q[5] = r[10]; q[6] = r[11];
-    }
     int rc;
-    if ((rc = upload((void**)&s->d_prim_plane, prim_plane.data(), prim_plane.size() * 4)) ||
-        (rc = upload((void**)&s->d_nodes, h.nodes.data(), h.nodes.size() * 4)) ||
+    if ((rc = upload((void**)&s->d_nodes, h.nodes.data(), h.nodes.size() * 4)) ||
         (rc = upload((void**)&s->d_tris, h.tri_rec.data(), h.tri_rec.size() * 4)) ||
         (rc = upload((void**)&s->d_slot_prim, h.slot_prim.data(), h.slot_prim.size() * 4)) ||
         (rc = upload((void**)&s->d_slot_label, h.slot_label.data(), h.slot_label.size() * 4)) ||
@@ -1525,8 +1530,29 @@ int lrc_scene_export_bvh(const lrc_scene* s, float* nodes16, uint32_t* slot_prim
     return LRC_OK;
 }
 
-int lrc_scene_export_array(const lrc_scene* s, int which, void* dst, uint64_t dst_bytes, uint64_t* out_bytes) {
-    if (!s) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_export_array: scene is NULL");
+// the plane table of the cloud rebuild, built on first use (enqueued on `st`)
+static int ensure_prim_plane(lrc_scene* s, hipStream_t st) {
+    if (s->d_prim_plane || s->info.num_triangles == 0) return LRC_OK;
+    const uint64_t T = s->info.num_triangles;
+    LRC_HIP(hipMalloc((void**)&s->d_prim_plane, T * 32));
+    LRC_HIP(hipMemsetAsync(s->d_prim_plane, 0, T * 32, st));
+    hipLaunchKernelGGL(prim_plane_kernel, dim3((uint32_t)((s->info.num_slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       (const float4*)s->d_tris, (const uint32_t*)s->d_slot_prim, (const uint32_t*)s->d_slot_label,
+                       (uint32_t)s->info.num_slots, (uint32_t)T, s->d_prim_plane);
+    LRC_HIP(hipGetLastError());
+    s->info.device_bytes += T * 32;
+    return LRC_OK;
+}
+
+int lrc_scene_export_array(const lrc_scene* cs, int which, void* dst, uint64_t dst_bytes, uint64_t* out_bytes) {
+    if (!cs) return fail(LRC_ERR_INVALID_ARG, "lrc_scene_export_array: scene is NULL");
+    lrc_scene* s = const_cast<lrc_scene*>(cs);
+    if (which == LRC_ARRAY_PRIM_PLANE) {
+        LRC_HIP(hipSetDevice(s->ctx->device));
+        int rc = ensure_prim_plane(s, nullptr);
+        if (rc) return rc;
+        LRC_HIP(hipStreamSynchronize(nullptr));
+    }
     const void* src = nullptr;
     uint64_t bytes = 0;
     const lrc_scene_info& in = s->info;
@@ -1571,6 +1597,8 @@ static int launch_trace_lab(lrc_scene* s, TraceParams& p, int gen, hipStream_t s
     if (gen == 3 && sector && !stats) {
         const lrc_grid& g = *s->cur_grid;
         SectorParams q{};
+        { int rc = ensure_prim_plane(s, st); if (rc) return rc; }      // the packet kernel keys rays by triangle row
+        p.prim_plane = s->d_prim_plane;
         q.tp = p;
         if (!s->d_slot_sphere && s->info.num_slots) {
             LRC_HIP(hipMalloc((void**)&s->d_slot_sphere, s->info.num_slots * 16));
@@ -2055,6 +2083,7 @@ static int prepare_rebuild(lrc_scene* s, const char* who, const double* d_poses1
     lrc_ctx::TileScratch& sc = ctx->cloud_scratch;
     int rc = ensure_tile_scratch(ctx, sc, ntiles);
     if (rc) return rc;
+    if ((rc = ensure_prim_plane(s, st))) return rc;
     if (sc.dirs_cap < N) {
         if (sc.d_dirs_soa) { (void)hipFree(sc.d_dirs_soa); sc.d_dirs_soa = nullptr; }
         sc.dirs_cap = 0;
@@ -2251,8 +2280,63 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
     // chunks only pay when there is enough to overlap, and need pose boundaries on 64-ray tiles (fused keep counts)
     uint64_t chunks = (P * N >= (1u << 20) && N % 64 == 0) ? (P < 4 ? P : 4) : 1;
     const float* noise = p.range_noise ? p.range_noise : s->opts.range_noise;   // staged in HBM by NoiseStage
-    // inputs were enqueued on the null stream by the caller: make them visible to the compute stream
-    LRC_HIP(hipStreamSynchronize(nullptr));
+    // (the callers enqueue their input copies on the compute stream: nothing to wait for here)
+    const uint64_t n_all = P * N;
+    const size_t row_bytes = (out->point3 ? 12 : 0) + (out->sem ? 2 : 0) + (out->ins ? 2 : 0) + (out->incident_deg ? 8 : 0) +
+                             (out->index ? 4 : 0) + (out->xyzl ? 16 : 0) + (out->range_origin ? 4 : 0);
+    if (chunks == 1 && capacity >= n_all && n_all * row_bytes <= (4u << 20)) {
+        // A small call -- the reference's own loop asks for ONE pose per call (s3dis_simulator.py:254-264): everything on
+        // one stream and ONE synchronisation.  The rows are copied at their worst-case length together with the counts
+        // (a pose's rows are ~1 MB: cheaper than a second round trip to learn the exact length first).
+        hipStream_t cs = ctx->s_compute;
+        TraceParams q = p;
+        q.out = st.rec;
+        lrc_scan_options saved = s->opts;
+        q.range_noise = nullptr;
+        if (noise) { s->opts.range_noise = noise; s->opts.range_noise_len = q.total; }
+        rc = launch_trace(s, q, gen, cs);
+        s->opts = saved;
+        if (rc) return rc;
+        if ((rc = lrc_compact_dev(ctx, P, N, &st.io, cs))) return rc;
+        LRC_HIP(hipMemcpyAsync(ctx->h_counts, st.io.counts, P * 8, hipMemcpyDeviceToHost, cs));
+        double* hs = (double*)(ctx->h_counts + ctx->h_counts_cap);
+        if (st.d_stats) {
+            float* rm = (float*)st.d_stats;            float* rs = (float*)(st.d_stats + P);
+            double* im = st.d_stats + 2 * P;           double* is = st.d_stats + 3 * P;
+            if (out->range_origin_mean || out->range_origin_std) {
+                hipLaunchKernelGGL(segment_stats_kernel<float>, dim3((uint32_t)P), dim3(256), 0, cs,
+                                   (const float*)st.io.out_range_origin, (const uint64_t*)st.io.counts, (uint64_t)0, P, rm, rs);
+                LRC_HIP(hipMemcpyAsync((float*)hs, rm, P * 4, hipMemcpyDeviceToHost, cs));
+                LRC_HIP(hipMemcpyAsync((float*)(hs + ctx->h_counts_cap), rs, P * 4, hipMemcpyDeviceToHost, cs));
+            }
+            if (out->incident_mean || out->incident_std) {
+                hipLaunchKernelGGL(segment_stats_kernel<double>, dim3((uint32_t)P), dim3(256), 0, cs,
+                                   (const double*)st.io.out_incident_deg, (const uint64_t*)st.io.counts, (uint64_t)0, P, im, is);
+                LRC_HIP(hipMemcpyAsync(hs + 2 * ctx->h_counts_cap, im, P * 8, hipMemcpyDeviceToHost, cs));
+                LRC_HIP(hipMemcpyAsync(hs + 3 * ctx->h_counts_cap, is, P * 8, hipMemcpyDeviceToHost, cs));
+            }
+            LRC_HIP(hipGetLastError());
+        }
+        if (out->point3) LRC_HIP(hipMemcpyAsync(out->point3, st.io.out_point3, n_all * 12, hipMemcpyDeviceToHost, cs));
+        if (out->sem) LRC_HIP(hipMemcpyAsync(out->sem, st.io.out_sem, n_all * 2, hipMemcpyDeviceToHost, cs));
+        if (out->ins) LRC_HIP(hipMemcpyAsync(out->ins, st.io.out_ins, n_all * 2, hipMemcpyDeviceToHost, cs));
+        if (out->incident_deg) LRC_HIP(hipMemcpyAsync(out->incident_deg, st.io.out_incident_deg, n_all * 8, hipMemcpyDeviceToHost, cs));
+        if (out->index) LRC_HIP(hipMemcpyAsync(out->index, st.io.out_index, n_all * 4, hipMemcpyDeviceToHost, cs));
+        if (out->xyzl) LRC_HIP(hipMemcpyAsync(out->xyzl, st.io.out_xyzl, n_all * 16, hipMemcpyDeviceToHost, cs));
+        if (out->range_origin) LRC_HIP(hipMemcpyAsync(out->range_origin, st.io.out_range_origin, n_all * 4, hipMemcpyDeviceToHost, cs));
+        LRC_HIP(hipStreamSynchronize(cs));
+        uint64_t K1 = 0;
+        for (uint64_t k = 0; k < P; ++k) {
+            out->counts[k] = ctx->h_counts[k];
+            K1 += ctx->h_counts[k];
+            if (out->range_origin_mean) out->range_origin_mean[k] = ((const float*)hs)[k];
+            if (out->range_origin_std) out->range_origin_std[k] = ((const float*)(hs + ctx->h_counts_cap))[k];
+            if (out->incident_mean) out->incident_mean[k] = hs[2 * ctx->h_counts_cap + k];
+            if (out->incident_std) out->incident_std[k] = hs[3 * ctx->h_counts_cap + k];
+        }
+        if (out_total) *out_total = K1;
+        return LRC_OK;
+    }
     uint64_t p0 = 0;
     for (uint64_t c = 0; c < chunks; ++c) {
         const uint64_t p1 = P * (c + 1) / chunks, np_ = p1 - p0, r0 = p0 * N;
@@ -2450,13 +2534,15 @@ static int scan_compact_impl(lrc_scene* s, const double* poses16, uint64_t P, co
     SyncUnlessOk guard;
     DevBuf dp, dd;
     int rc;
+    if ((rc = ensure_streams(s->ctx))) return rc;
+    hipStream_t in = s->ctx->s_compute;       // inputs travel on the stream that consumes them
     if ((rc = dp.get(s->ctx, kPoolPoses, P * 128))) return rc;
-    LRC_HIP(hipMemcpyAsync(dp.p, poses16, P * 128, hipMemcpyHostToDevice, nullptr));
+    LRC_HIP(hipMemcpyAsync(dp.p, poses16, P * 128, hipMemcpyHostToDevice, in));
     if (d_dirs3) {
         dd.p = (void*)d_dirs3; dd.pooled = true;            // resident table (lrc_table): nothing to upload
     } else {
         if ((rc = dd.get(s->ctx, kPoolDirs, N * 24))) return rc;
-        LRC_HIP(hipMemcpyAsync(dd.p, dirs3, N * 24, hipMemcpyHostToDevice, nullptr));
+        LRC_HIP(hipMemcpyAsync(dd.p, dirs3, N * 24, hipMemcpyHostToDevice, in));
     }
     FrameStage st;
     if ((rc = st.alloc(s->ctx, *out, P, n))) return rc;
@@ -2506,12 +2592,14 @@ int lrc_scan_angles_compact(lrc_scene* s, const double* poses16, uint64_t P, con
     SyncUnlessOk guard;
     DevBuf dp, da, dk;
     int rc;
+    if ((rc = ensure_streams(s->ctx))) return rc;
+    hipStream_t in = s->ctx->s_compute;
     if ((rc = dp.get(s->ctx, kPoolPoses, P * 128)) || (rc = da.get(s->ctx, kPoolAngles, n * 16))) return rc;
-    LRC_HIP(hipMemcpyAsync(dp.p, poses16, P * 128, hipMemcpyHostToDevice, nullptr));
-    LRC_HIP(hipMemcpyAsync(da.p, angles2, n * 16, hipMemcpyHostToDevice, nullptr));
+    LRC_HIP(hipMemcpyAsync(dp.p, poses16, P * 128, hipMemcpyHostToDevice, in));
+    LRC_HIP(hipMemcpyAsync(da.p, angles2, n * 16, hipMemcpyHostToDevice, in));
     if (keep) {
         if ((rc = dk.get(s->ctx, kPoolKeep, n))) return rc;
-        LRC_HIP(hipMemcpyAsync(dk.p, keep, n, hipMemcpyHostToDevice, nullptr));
+        LRC_HIP(hipMemcpyAsync(dk.p, keep, n, hipMemcpyHostToDevice, in));
     }
     FrameStage st;
     if ((rc = st.alloc(s->ctx, *out, P, n))) return rc;
@@ -2540,12 +2628,14 @@ int lrc_scan_rays_compact(lrc_scene* s, const float* rays6, const uint8_t* keep,
     SyncUnlessOk guard;
     DevBuf dr, dc, dk;
     int rc;
+    if ((rc = ensure_streams(s->ctx))) return rc;
+    hipStream_t in = s->ctx->s_compute;
     if ((rc = dr.get(s->ctx, kPoolRays, n * 24)) || (rc = dc.get(s->ctx, kPoolCen, P * 24))) return rc;
-    LRC_HIP(hipMemcpyAsync(dr.p, rays6, n * 24, hipMemcpyHostToDevice, nullptr));
-    LRC_HIP(hipMemcpyAsync(dc.p, centers3, P * 24, hipMemcpyHostToDevice, nullptr));
+    LRC_HIP(hipMemcpyAsync(dr.p, rays6, n * 24, hipMemcpyHostToDevice, in));
+    LRC_HIP(hipMemcpyAsync(dc.p, centers3, P * 24, hipMemcpyHostToDevice, in));
     if (keep) {
         if ((rc = dk.get(s->ctx, kPoolKeep, n))) return rc;
-        LRC_HIP(hipMemcpyAsync(dk.p, keep, n, hipMemcpyHostToDevice, nullptr));
+        LRC_HIP(hipMemcpyAsync(dk.p, keep, n, hipMemcpyHostToDevice, in));
     }
     FrameStage st;
     if ((rc = st.alloc(s->ctx, *out, P, n))) return rc;

@@ -33,7 +33,6 @@ struct DeviceScene {               // one allocation (`slab`), the arrays point 
     uint32_t* slot_prim = nullptr;
     uint32_t* slot_label = nullptr;
     float* slot_box = nullptr;     // LRC_EDGE_TRIS: num_slots x 24 B
-    void* prim_plane = nullptr;    // num_triangles x 32 B
     void* nodes_q = nullptr;       // num_nodes x 32 B, or NULL
     void* nodes_n = nullptr;       // num_nodes x 64 B, or NULL
     uint64_t num_nodes = 0, num_leaves = 0, num_slots = 0;

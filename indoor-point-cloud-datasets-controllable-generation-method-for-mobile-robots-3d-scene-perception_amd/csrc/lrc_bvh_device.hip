@@ -959,11 +959,11 @@ __global__ __launch_bounds__(256) void k_write_nodes(const TNode* nodes, uint32_
     if (threadIdx.x == 0) { infl_part[blockIdx.x] = s_sum[0]; infl_cnt[blockIdx.x] = s_cnt[0]; }
 }
 
-// 48-byte triangle records in slot order, ids, labels, the per-row plane table (same expressions as bvh_build.cpp)
+// 48-byte triangle records in slot order, ids, labels (same expressions as bvh_build.cpp)
 __global__ __launch_bounds__(256) void k_tri_records(const float* verts3, const uint32_t* tris3, const uint16_t* sem,
                                                      const uint16_t* ins, const uint32_t* final_id, uint32_t T,
                                                      float4* out_tris, uint32_t* slot_prim, uint32_t* slot_label,
-                                                     float4* prim_plane, float* slot_box) {
+                                                     float* slot_box) {
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s >= T + 3u) return;
     float4* o = out_tris + (size_t)s * 3;
@@ -996,8 +996,6 @@ __global__ __launch_bounds__(256) void k_tri_records(const float* verts3, const 
     const uint32_t lab = (sem ? (uint32_t)sem[id] : 0u) | ((ins ? (uint32_t)ins[id] : 0u) << 16);
     slot_prim[s] = id;
     slot_label[s] = lab;
-    prim_plane[(size_t)id * 2] = make_float4(a[0], a[1], a[2], __uint_as_float(lab));
-    prim_plane[(size_t)id * 2 + 1] = make_float4(nx, ny, nz, 0.0f);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
@@ -1236,13 +1234,13 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     }
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_nodes = al((size_t)nn * 64), b_q = qg.enabled ? al((size_t)nn * 32) : 0, b_n = qg.enabled ? al((size_t)nn * 64) : 0;
-    const size_t b_tris = al(((size_t)T + 3) * 48), b_id = al((size_t)T * 4), b_plane = al((size_t)T * 32);
+    const size_t b_tris = al(((size_t)T + 3) * 48), b_id = al((size_t)T * 4);
 #ifdef LRC_EDGE_TRIS
     const size_t b_box = al((size_t)T * 24);
 #else
     const size_t b_box = 0;
 #endif
-    const size_t slab_bytes = b_nodes + b_q + b_n + b_tris + 2 * b_id + b_plane + b_box;
+    const size_t slab_bytes = b_nodes + b_q + b_n + b_tris + 2 * b_id + b_box;
     void* slab = nullptr;
     DB_HIP(hipMalloc(&slab, slab_bytes));
     char* sp = (char*)slab;
@@ -1253,7 +1251,6 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     out->tris = sp; sp += b_tris;
     out->slot_prim = (uint32_t*)sp; sp += b_id;
     out->slot_label = (uint32_t*)sp; sp += b_id;
-    out->prim_plane = sp; sp += b_plane;
     out->slot_box = b_box ? (float*)sp : nullptr;
     auto bail = [&](int rc) { (void)hipFree(slab); *out = DeviceScene(); return rc; };
 
@@ -1270,7 +1267,7 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     hipLaunchKernelGGL(k_write_nodes, dim3(nblk), dim3(256), 0, st, (const TNode*)nodes, nn, (const uint32_t*)new_of_old,
                        (float4*)out->nodes, (uint4*)out->nodes_q, (float4*)out->nodes_n, qg, infl_part, infl_cnt, qfail, final_id);
     hipLaunchKernelGGL(k_tri_records, dim3((T + 3 + 255) / 256), dim3(256), 0, st, d_verts, d_tris, d_sem, d_ins,
-                       (const uint32_t*)final_id, T, (float4*)out->tris, out->slot_prim, out->slot_label, (float4*)out->prim_plane, out->slot_box);
+                       (const uint32_t*)final_id, T, (float4*)out->tris, out->slot_prim, out->slot_label, out->slot_box);
     {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { if (err) *err = std::string("device BVH build: ") + hipGetErrorString(e); return bail(LRC_ERR_HIP); }

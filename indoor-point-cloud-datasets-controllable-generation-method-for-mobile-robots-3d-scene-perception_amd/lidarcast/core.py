@@ -58,6 +58,11 @@ class PinnedPool:
         self._max_out = int(max_outstanding_bytes)   # page-locked bytes callers may hold at once; beyond it take()
         self.outstanding = 0                          # hands out ordinary (pageable) memory instead of locking more
         self.allocations = 0       # hipHostMalloc calls so far (tests / bench bookkeeping)
+        # take() runs on the caller's thread, _release() on whichever thread drops the last view of a block (a pool
+        # worker holding frame slices, the garbage collector): the free lists and counters are guarded
+        # (re-entrant: dropping the last reference to a slab inside a guarded section runs _release on the spot)
+        import threading
+        self._lock = threading.RLock()
 
     @staticmethod
     def _klass(nbytes):
@@ -66,21 +71,117 @@ class PinnedPool:
             k <<= 1
         return k
 
+    SLAB_BYTES = 32 << 20        # requests up to a quarter of this are carved out of shared slabs
+    _slab = None                 # [raw ctypes array, fill] of the slab currently being carved
+
+    def _new_block(self, k):
+        """A page-locked block of k bytes: from the free list, else hipHostMalloc.  None when the cap is reached."""
+        with self._lock:
+            lst = self._free.get(k)
+            if not lst and self.outstanding + k > self._max_out:
+                return None
+            self.outstanding += k
+            ptr = None
+            if lst:
+                ptr = lst.pop()
+                self._free_bytes -= k
+        if ptr is None:
+            p = C.c_void_p()
+            try:
+                check(self._ctx._lib.lrc_host_alloc(self._ctx._h, k, C.byref(p)), "lrc_host_alloc")
+            except Exception:
+                with self._lock:
+                    self.outstanding -= k
+                raise
+            ptr = p.value
+            with self._lock:
+                self.allocations += 1
+        return ptr
+
+    def _wrap_slab(self, ptr):
+        import weakref
+        raw = (C.c_uint8 * self.SLAB_BYTES).from_address(ptr)
+        weakref.finalize(raw, PinnedPool._release, weakref.ref(self), ptr, self.SLAB_BYTES, self._ctx)
+        return raw
+
+    def _prefetch_slab(self):
+        """Page-lock the NEXT slab on a helper thread (locking pages costs ~0.15 ms per MB; the library call releases the
+        GIL): a caller that keeps every frame -- the reference's loop does -- then finds it ready."""
+        import threading
+
+        def work():
+            try:
+                ptr = self._new_block(self.SLAB_BYTES)
+            except Exception:
+                ptr = None
+            with self._lock:
+                self._spare = ptr
+                self._prefetching = False
+        with self._lock:
+            if self._prefetching or self._spare is not None:
+                return
+            self._prefetching = True
+        threading.Thread(target=work, daemon=True).start()
+
+    _spare = None
+    _prefetching = False
+
+    def _take_small(self, nbytes):
+        """A slice of a page-locked slab (bump allocation, 256-byte aligned).  A per-waypoint caller -- the reference's own
+        loop keeps every frame it is handed -- would otherwise pay a hipHostMalloc per call; this way it pays one per
+        32 MB, and that one ahead of time on a helper thread.  A slab returns to the pool when the last array cut from
+        it is dropped."""
+        n = (int(nbytes) + 255) & ~255
+        want_prefetch = False
+        with self._lock:
+            sl = self._slab
+            if sl is not None and sl[1] + n <= self.SLAB_BYTES:
+                off = sl[1]
+                sl[1] += n
+                want_prefetch = sl[1] > self.SLAB_BYTES // 2 and self._spare is None and not self._prefetching
+                out = np.frombuffer(sl[0], dtype=np.uint8, count=max(int(nbytes), 1), offset=off)
+            else:
+                out = None
+                self._slab = None          # the old slab lives on through the arrays cut from it
+                ptr, self._spare = self._spare, None
+        if out is not None:
+            if want_prefetch:
+                self._prefetch_slab()
+            return out
+        if ptr is None:
+            ptr = self._new_block(self.SLAB_BYTES)
+            if ptr is None:
+                return np.empty(max(int(nbytes), 1), dtype=np.uint8)
+        raw = self._wrap_slab(ptr)
+        with self._lock:
+            self._slab = [raw, n]
+        return np.frombuffer(raw, dtype=np.uint8, count=max(int(nbytes), 1), offset=0)
+
     def take(self, nbytes):
         import weakref
+        if int(nbytes) <= self.SLAB_BYTES // 4:
+            return self._take_small(nbytes)
         k = self._klass(max(int(nbytes), 1))
-        lst = self._free.get(k)
-        if not lst and self.outstanding + k > self._max_out:
-            return np.empty(k, dtype=np.uint8)      # a caller hoarding frames: stop locking pages, stay correct
-        self.outstanding += k
-        if lst:
-            ptr = lst.pop()
-            self._free_bytes -= k
-        else:
+        with self._lock:
+            lst = self._free.get(k)
+            if not lst and self.outstanding + k > self._max_out:
+                return np.empty(k, dtype=np.uint8)      # a caller hoarding frames: stop locking pages, stay correct
+            self.outstanding += k
+            ptr = None
+            if lst:
+                ptr = lst.pop()
+                self._free_bytes -= k
+        if ptr is None:
             p = C.c_void_p()
-            check(self._ctx._lib.lrc_host_alloc(self._ctx._h, k, C.byref(p)), "lrc_host_alloc")
+            try:
+                check(self._ctx._lib.lrc_host_alloc(self._ctx._h, k, C.byref(p)), "lrc_host_alloc")
+            except Exception:
+                with self._lock:
+                    self.outstanding -= k
+                raise
             ptr = p.value
-            self.allocations += 1
+            with self._lock:
+                self.allocations += 1
         raw = (C.c_uint8 * k).from_address(ptr)
         weakref.finalize(raw, PinnedPool._release, weakref.ref(self), ptr, k, self._ctx)
         return np.frombuffer(raw, dtype=np.uint8, count=k)
@@ -88,21 +189,36 @@ class PinnedPool:
     @staticmethod
     def _release(pool_ref, ptr, k, ctx):
         pool = pool_ref()
+        keep = False
         if pool is not None:
-            pool.outstanding -= k
-        if pool is not None and pool._free_bytes + k <= pool._max_free and getattr(ctx, "_h", None):
-            pool._free.setdefault(k, []).append(ptr)
-            pool._free_bytes += k
-        elif getattr(ctx, "_h", None):
+            with pool._lock:
+                pool.outstanding -= k
+                if pool._free_bytes + k <= pool._max_free and getattr(ctx, "_h", None):
+                    pool._free.setdefault(k, []).append(ptr)
+                    pool._free_bytes += k
+                    keep = True
+        if not keep and getattr(ctx, "_h", None):
             ctx._lib.lrc_host_free(ctx._h, C.c_void_p(ptr))
 
     def clear(self):
-        for lst in self._free.values():
+        import time
+        for _ in range(200):               # a prefetch in flight finishes first (its block must not outlive the context)
+            with self._lock:
+                if not self._prefetching:
+                    break
+            time.sleep(0.005)
+        with self._lock:
+            self._slab = None
+            spare, self._spare = self._spare, None
+            if spare is not None:
+                self.outstanding -= self.SLAB_BYTES
+            lists = list(self._free.values()) + ([[spare]] if spare is not None else [])
+            self._free = {}
+            self._free_bytes = 0
+        for lst in lists:
             for ptr in lst:
                 if getattr(self._ctx, "_h", None):
                     self._ctx._lib.lrc_host_free(self._ctx._h, C.c_void_p(ptr))
-        self._free.clear()
-        self._free_bytes = 0
 
 
 class Context:
@@ -421,7 +537,7 @@ class Scene:
         return outs
 
     # ---- straight to frames ---------------------------------------------------------------------
-    PINNED_MIN_BYTES = 4 << 20      # frame arrays at least this large are taken from the page-locked pool
+    PINNED_MIN_BYTES = 0            # every frame array comes from the page-locked pool (small ones are slab slices)
 
     def _frames_begin(self, P, n, want, capacity):
         cap = int(n if capacity is None else capacity)

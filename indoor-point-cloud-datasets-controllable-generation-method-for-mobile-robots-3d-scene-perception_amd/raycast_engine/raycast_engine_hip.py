@@ -7,6 +7,7 @@ CPU path: without the built library or without a GPU the constructor raises, whi
 caller turns into its own fallback decision (s3dis_simulator.py:66-74).
 """
 import hashlib
+import itertools
 import weakref
 
 import numpy as np
@@ -428,10 +429,13 @@ class RaycastEngineHIP(RaycastEngineBase):
 
     @staticmethod
     def split_frames(frames, name):
-        """Per-pose views of one attribute of a scan_frames result (no copy)."""
-        ends = np.cumsum(frames["counts"])
+        """Per-pose views of one attribute of a scan_frames result (no copy); a tuple of names gives one list each."""
+        counts = frames["counts"].tolist()
+        ends = list(itertools.accumulate(counts))
+        if isinstance(name, (tuple, list)):
+            return [[frames[n][e - c:e] for c, e in zip(counts, ends)] for n in name]
         a = frames[name]
-        return [a[e - c:e] for c, e in zip(frames["counts"], ends)]
+        return [a[e - c:e] for c, e in zip(counts, ends)]
 
     def scan_lidars(self, lidars, mesh, want=("t", "point3", "incident_deg")):
         """Several sensor poses whose rays come from the host generator (dual-axis sensor: seeded noise and

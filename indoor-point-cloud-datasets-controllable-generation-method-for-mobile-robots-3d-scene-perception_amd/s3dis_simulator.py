@@ -11,6 +11,7 @@ reference loop that a drop-in must reproduce to give the same statistics (``bug_
 the incident angles are overwritten with zeros (:266-269) and the range statistics are norms from the
 WORLD origin, not from the sensor (:283-284).
 """
+import itertools
 import json
 import time
 from pathlib import Path
@@ -150,18 +151,18 @@ class S3DISSimulator:
 
     def _quality_from_stats(self, fr, total_points_per_scan, room_volume):
         """ScanQuality of every frame from the per-pose statistics the device computed with numpy's arithmetic."""
-        out = []
+        counts = fr["counts"].tolist()
         zero = np.float64(0.0)
-        for i, k in enumerate(fr["counts"].tolist()):
+        P = len(counts)
+        am = [zero] * P if self.bug_compatible else list(fr["incident_mean"])
+        asd = [zero] * P if self.bug_compatible else list(fr["incident_std"])
+        rm, rs = list(fr["range_origin_mean"]), list(fr["range_origin_std"])      # numpy scalars, as np.mean returns them
+        out = []
+        for i, k in enumerate(counts):
             if k == 0:
-                out.append(ScanQuality(coverage_ratio=0.0, num_points=0, incident_angle_mean=0, incident_angle_std=0,
-                                       scan_density=0.0, range_mean=0, range_std=0))
-                continue
-            am = zero if self.bug_compatible else fr["incident_mean"][i]
-            asd = zero if self.bug_compatible else fr["incident_std"][i]
-            out.append(ScanQuality(coverage_ratio=k / total_points_per_scan, num_points=k, incident_angle_mean=am,
-                                   incident_angle_std=asd, scan_density=k / room_volume,
-                                   range_mean=fr["range_origin_mean"][i], range_std=fr["range_origin_std"][i]))
+                out.append(ScanQuality(0.0, 0, 0, 0, 0.0, 0, 0))
+            else:
+                out.append(ScanQuality(k / total_points_per_scan, k, am[i], asd[i], k / room_volume, rm[i], rs[i]))
         return out
 
     def _quality_many(self, points, angles, total_points_per_scan, room_volume, ranges):
@@ -213,8 +214,10 @@ class S3DISSimulator:
         engine = self.raycast_engine
         # the per-frame mean / std of the ScanQuality records come from the device as well, computed with numpy's own
         # summation order (csrc/lrc_stats.h), so neither the range column nor a host reduction is needed
-        want = ("point3", "sem", "ins", "range_origin_stats") + \
-            (() if self.bug_compatible else ("incident_deg", "incident_stats"))
+        from lidarcast.npmodel import reductions_match
+        device_stats = reductions_match()       # a numpy that sums differently reduces the columns itself
+        want = ("point3", "sem", "ins", "range_origin_stats" if device_stats else "range_origin") + \
+            (() if self.bug_compatible else (("incident_deg", "incident_stats") if device_stats else ("incident_deg",)))
         batched = isinstance(self.lidar_config, Indoor8LineLidarIntrinsics) and \
             self.lidar_config.vertical_degrees is not None
         device_gen = bool(self.config.get("raycast_engine", {}).get("device_ray_generation", False))
@@ -252,21 +255,22 @@ class S3DISSimulator:
             lidars = [create_lidar(self.lidar_config, wp.to_pose_matrix()) for wp in waypoints]
             seg, off = engine.scan_lidars(lidars, mesh, want=("t", "point3", "incident_deg", "sem", "ins"))
         if fr is not None:
-            pts_f, sem_f, ins_f = (engine.split_frames(fr, a) for a in ("point3", "sem", "ins"))
             if self.bug_compatible:            # one zero block, frames take views of it (reference :266-269)
                 fr["incident_deg"] = np.zeros(fr["total"])
-            ang_f = engine.split_frames(fr, "incident_deg")
+            counts_l = fr["counts"].tolist()
+            ends_l = list(itertools.accumulate(counts_l))
+            pts_f, sem_f, ins_f, ang_f = ([fr[a][e - c:e] for c, e in zip(counts_l, ends_l)]
+                                          for a in ("point3", "sem", "ins", "incident_deg"))
             if "range_origin_mean" in fr:      # statistics from the device
                 qual = self._quality_from_stats(fr, total, volume)
             else:
                 # (sharded scans) per-frame statistics are numpy reductions over 10^4..10^5 values each; they release
                 # the GIL, so the frames of a long trajectory are reduced side by side (same numpy calls, same values)
                 qual = self._quality_many(pts_f, ang_f, total, volume, engine.split_frames(fr, "range_origin"))
-        for i, wp in enumerate(waypoints):
-            if fr is not None:
-                sim_scene.append_frame(S3DISSimFrame(i, pts_f[i], ang_f[i], qual[i], semantic_labels=sem_f[i],
-                                                     instance_labels=ins_f[i]))
-                continue
+        if fr is not None:
+            sim_scene.frames.extend(map(S3DISSimFrame, range(len(waypoints)), pts_f, ang_f, qual, itertools.repeat(None),
+                                        sem_f, ins_f))
+        for i, wp in enumerate(waypoints if fr is None else ()):
             a, b = off[i], off[i + 1]
             keep = seg["t"][a:b] != np.inf
             points, angles = seg["point3"][a:b][keep], seg["incident_deg"][a:b][keep]

@@ -128,9 +128,26 @@ class TrajectoryGeneratorBase(ABC):
 
 def poses_from_waypoints(waypoints: List[Waypoint]) -> np.ndarray:
     """(P,4,4) float64 stack of ``to_pose_matrix()``."""
-    if len(waypoints) == 0:
+    n = len(waypoints)
+    if n == 0:
         return np.zeros((0, 4, 4))
-    return np.stack([w.to_pose_matrix() for w in waypoints])
+    # one array assembly instead of n small ones; the trigonometry is still evaluated per DISTINCT yaw with the scalar
+    # np.cos / np.sin calls of to_pose_matrix (auto trajectories have a single yaw, trajectory/auto_trajectory_generator.py)
+    out = np.zeros((n, 4, 4))
+    out[:, 0, 0] = out[:, 1, 1] = out[:, 2, 2] = out[:, 3, 3] = 1.0
+    out[:, 0, 3] = [w.x for w in waypoints]
+    out[:, 1, 3] = [w.y for w in waypoints]
+    out[:, 2, 3] = [w.z for w in waypoints]
+    trig = {}
+    cs = np.empty((n, 2))
+    for i, w in enumerate(waypoints):
+        t = trig.get(w.yaw)
+        if t is None:
+            t = trig[w.yaw] = (np.cos(w.yaw), np.sin(w.yaw))
+        cs[i] = t
+    out[:, 0, 0], out[:, 0, 1] = cs[:, 0], -cs[:, 1]
+    out[:, 1, 0], out[:, 1, 1] = cs[:, 1], cs[:, 0]
+    return out
 
 
 def line_trajectory(start, end, num_waypoints: int, yaw: float = 0.0) -> List[Waypoint]:

@@ -7,42 +7,7 @@ import numpy as np
 import pytest
 
 
-def _pw(a):
-    n, T = len(a), a.dtype.type
-    if n < 8:
-        r = T(0)
-        for x in a:
-            r = T(r + x)
-        return r
-    if n <= 128:
-        body = a[:n - n % 8].reshape(-1, 8)
-        r = body[0].copy()
-        for row in body[1:]:
-            r = (r + row).astype(a.dtype)
-        res = T(T(T(r[0] + r[1]) + T(r[2] + r[3])) + T(T(r[4] + r[5]) + T(r[6] + r[7])))
-        for x in a[n - n % 8:]:
-            res = T(res + x)
-        return res
-    n2 = n // 2
-    n2 -= n2 % 8
-    return T(_pw(a[:n2]) + _pw(a[n2:]))
-
-
-def model_sum(a):
-    res = None
-    for i in range(0, len(a), 8192):
-        c = _pw(a[i:i + 8192])
-        res = c if res is None else a.dtype.type(res + c)
-    return res
-
-
-def model_mean_std(a):
-    T = a.dtype.type
-    n = T(len(a))
-    mean = T(model_sum(a) / n)
-    x = (a - mean).astype(a.dtype)
-    x = (x * x).astype(a.dtype)
-    return mean, T(np.sqrt(T(model_sum(x) / n)))
+from lidarcast.npmodel import model_mean_std, model_sum, reductions_match   # the product's own statement of the model
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -59,6 +24,11 @@ def test_model_matches_numpy(dtype):
     big = (rng.random(100000) * 5).astype(dtype)
     v = big[12345:12345 + 33333]
     assert model_sum(v) == np.add.reduce(v) and model_mean_std(v)[1] == np.std(v)
+
+
+def test_engine_self_check_accepts_this_numpy():
+    """What the simulator asks before it trusts the device statistics (lidarcast.npmodel.reductions_match)."""
+    assert reductions_match() is True
 
 
 def test_ragged_chunk_slot_scheme_equals_the_recursion():

@@ -30,6 +30,8 @@ echo "== C4" >> $O/measure.log
 timeout -k 10 400 python3 tools/c4_time.py 256 >> $O/measure.log 2>&1
 echo "== per waypoint" >> $O/measure.log
 timeout -k 10 200 python3 tools/per_waypoint_time.py >> $O/measure.log 2>&1
+echo "== run_simulation profile" >> $O/measure.log
+timeout -k 10 200 python3 tools/run_sim_profile.py >> $O/measure.log 2>&1
 echo "== bench" >> $O/measure.log
 timeout -k 10 300 python3 bench.py > $O/bench1.json 2>> $O/measure.log
 tail -c 600 $O/bench1.json >> $O/measure.log

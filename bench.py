@@ -253,6 +253,8 @@ def main():
     dist_path = world > 1 or args.dist_selftest
     want = ("t", "prim", "normal3", "point3", "sem", "ins", "tile_count")
     hits = lidarcast.DeviceHits(n, dev, want=want)
+    # N > 1: the own rows of scan i are scattered from its local records while scan i+1 is traced -> two record sets
+    hits_sets = [hits, lidarcast.DeviceHits(n, dev, want=want)] if dist_path else [hits]
     # scene cloud: compacted 16-byte rows (x, y, z, sem|ins<<16) in np.vstack order + per-pose counts.
     cloud = torch.empty((n * job, 4), dtype=torch.float32, device=dev)
     counts = torch.zeros(P * job, dtype=torch.int64, device=dev)
@@ -291,12 +293,22 @@ def main():
         side = torch.cuda.Stream(device=dev)
         rebuilt = [None, None]                   # event: the rebuild that last READ gathers[k].all_slabs is done
 
+    own_ios = []
+    for h in hits_sets:                          # the rank's own records, as the own-row scatter of the rebuild reads them
+        o = LrcCompactIO()
+        o.t, o.point3, o.sem, o.ins = h["t"].data_ptr(), h["point3"].data_ptr(), h["sem"].data_ptr(), h["ins"].data_ptr()
+        own_ios.append(o)
+    own_slab = rank if world > 1 else 0
+
     def rebuild(k):
         g = gathers[k]
         with torch.cuda.stream(side):
             g.work.wait()                        # the side stream waits for the collective of that scan
+            # the other ranks' rows are rebuilt from their triangle ids; this rank's own rows come straight from the
+            # records its trace wrote (lrc_cloud_from_prims_own_dev): nothing is computed twice
             scene.cloud_from_prims_dev(d_all_poses, d_dirs, g.all_prims, cloud, counts, g.all_tile_counts,
-                                       poses_per_slab=P, slab_stride_bytes=g.stride_bytes, stream=side.cuda_stream)
+                                       poses_per_slab=P, slab_stride_bytes=g.stride_bytes, stream=side.cuda_stream,
+                                       own_slab=own_slab, own_io=own_ios[k])
             ev = torch.cuda.Event()
             ev.record(side)
         rebuilt[k] = ev
@@ -320,9 +332,10 @@ def main():
             g.work.wait()                        # the collective that last read this send slab (scan i-2) is done
         if rebuilt[k] is not None:
             main.wait_event(rebuilt[k])          # ... and so is the rebuild that read its receive buffer
-        hits.struct.prim = g.prim.data_ptr()     # the 36-byte record is complete; its id column IS the send slab
-        hits.struct.tile_count = g.tile_count.data_ptr()
-        scene.scan_poses_dev(d_poses, d_dirs, hits, sensor.max_range, stream)
+        hk = hits_sets[k]
+        hk.struct.prim = g.prim.data_ptr()       # the 36-byte record is complete; its id column IS the send slab
+        hk.struct.tile_count = g.tile_count.data_ptr()
+        scene.scan_poses_dev(d_poses, d_dirs, hk, sensor.max_range, stream)
         if timed:
             e1.record()
             k_events.append((e0, e1))
@@ -478,7 +491,8 @@ def main():
                 "step": "in-kernel ray generation + BVH traversal + hit write-back (36 B/ray) + "
                         + ("stable compaction into the scene cloud (16 B/hit)" if world == 1 else
                            "one RCCL all-gather of the hit triangle ids (4 B/ray + 4 B per 64 rays of keep counts) + "
-                           "rebuild of the whole scene cloud (16 B/hit, all ranks' poses) on every GPU"),
+                           "assembly of the whole scene cloud (16 B/hit) on every GPU: the other ranks' rows rebuilt "
+                           "from their ids, the own rows scattered from the local records"),
             },
             "roofline": roofline,
         }

@@ -412,6 +412,21 @@ int lrc_cloud_from_prims_dev(lrc_scene* scene, const double* d_poses16, uint64_t
                              const uint32_t* d_tile_count, uint64_t poses_per_slab, uint64_t slab_stride_bytes,
                              float* d_out_xyzl, uint64_t* d_counts, void* stream);
 
+/* The same when the caller's own slab of poses does not need rebuilding: its rows come from the local records the trace
+ * kernel wrote (own->t, own->point3, own->sem, own->ins: fixed-stride arrays of poses_per_slab x rays_per_pose entries),
+ * scattered to their place in the assembled cloud; only the other slabs are rebuilt from ids.  Same output bytes.
+ * Needs the senders' per-wave keep counts (d_tile_count, rays_per_pose % 64 == 0). */
+int lrc_cloud_from_prims_own_dev(lrc_scene* scene, const double* d_poses16, uint64_t num_poses, const double* d_dirs3,
+                                 uint64_t rays_per_pose, const uint32_t* d_prim, const uint32_t* d_tile_count,
+                                 uint64_t poses_per_slab, uint64_t slab_stride_bytes, uint64_t own_slab,
+                                 const lrc_compact_io* own, float* d_out_xyzl, uint64_t* d_counts, void* stream);
+
+/* Per-pose mean / std of |p| (float32, from the WORLD origin, numpy's arithmetic: lrc_stats.h) over the assembled
+ * (x, y, z, label) rows of a scan: the ScanQuality range statistics (s3dis_simulator.py:283-286) of a cloud that was
+ * assembled on the device.  d_range: scratch of max_rows floats (receives |p| per row). */
+int lrc_cloud_range_stats_dev(lrc_ctx* ctx, const float* d_xyzl, const uint64_t* d_counts, uint64_t num_poses,
+                              uint64_t max_rows, float* d_range, float* d_mean, float* d_std, void* stream);
+
 /* ---- nearest annotated point --------------------------------------
  * Exact 1-nearest-neighbour lookup of float32 query points in a float64 annotated cloud, float64 distances,
  * ties to the smaller row.  Replaces sklearn NearestNeighbors(n_neighbors=1, algorithm='ball_tree')

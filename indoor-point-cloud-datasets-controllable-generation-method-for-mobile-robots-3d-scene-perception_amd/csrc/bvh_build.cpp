@@ -320,16 +320,12 @@ void build_bvh(const float* verts3, uint64_t V, const uint32_t* tris3, uint64_t 
         float e1[3], e2[3];
         for (int k = 0; k < 3; ++k) { e1[k] = v0[k] - v1[k]; e2[k] = v2[k] - v0[k]; }
         float* r = &o.tri_rec[s * kTriFloats];
-#ifdef LRC_EDGE_TRIS
         for (int k = 0; k < 3; ++k) { r[k] = v0[k]; r[3 + k] = e1[k]; r[6 + k] = e2[k]; }
         if (o.slot_box.empty()) o.slot_box.assign(T * 6, 0.0f);
         for (int k = 0; k < 3; ++k) {
             o.slot_box[s * 6 + k] = fmin_t(fmin_t(v0[k], v1[k]), v2[k]);
             o.slot_box[s * 6 + 3 + k] = fmax_t(fmax_t(v0[k], v1[k]), v2[k]);
         }
-#else
-        for (int k = 0; k < 3; ++k) { r[k] = v0[k]; r[3 + k] = v1[k]; r[6 + k] = v2[k]; }
-#endif
         // Ng = cross(e2, e1), component = fma(a_j, b_k, -(a_k * b_j))
         r[9]  = fmaf_(e2[1], e1[2], -(e2[2] * e1[1]));
         r[10] = fmaf_(e2[2], e1[0], -(e2[0] * e1[2]));

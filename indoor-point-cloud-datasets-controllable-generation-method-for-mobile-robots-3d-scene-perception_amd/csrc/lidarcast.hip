@@ -69,9 +69,9 @@ enum PoolSlot { kPoolRays = 0, kPoolT, kPoolPrim, kPoolNormal, kPoolPoint, kPool
                 kPoolAngles, kPoolKeep, kPoolTile, kPoolCounts, kPoolOutPoint, kPoolOutSem, kPoolOutIns, kPoolOutInc,
                 kPoolOutIdx, kPoolOutXyzl, kPoolOutRange, kPoolStats, kPoolFrameStats, kPoolSlots };
 
-#ifndef LRC_LEAFW2_WAVES
-#define LRC_LEAFW2_WAVES 0   // A/B builds: 8 = hold the leaf-pair kernel (laboratory, LRC_LEAFW=2) to 8 waves per SIMD
-#endif
+// triangle records fetched per leaf round trip by the product kernels.  With edge records the pair fits 64 VGPRs, i.e. 8
+// waves per SIMD: -2...-4 % trace time on all benchmark scenes against one record per round trip.
+constexpr int kLeafW = 2;
 #ifndef LRC_REBUILD_R
 #define LRC_REBUILD_R 2      // tiles (of 64 entries) one wave of the cloud rebuild handles (1, 2, 4, 8 measured equal)
 #endif
@@ -115,7 +115,7 @@ struct lrc_scene {
     float4* d_tris = nullptr;
     uint32_t* d_slot_prim = nullptr;
     uint32_t* d_slot_label = nullptr;
-    float* d_slot_box = nullptr;      // LRC_EDGE_TRIS: per leaf slot the triangle's exact vertex box (lo xyz, hi xyz)
+    float* d_slot_box = nullptr;      // per leaf slot the triangle's exact vertex box (lo xyz, hi xyz)
     float4* d_prim_plane = nullptr;   // per caller's triangle row: (v0, label bits), (Ng, 0): lrc_cloud_from_prims_dev
     float4* d_slot_sphere = nullptr;  // per leaf slot: centre of the triangle's box + bounding radius (sector_kernel)
     // quantised node images of the SAME tree ("32-byte nodes"): child boxes on a 15-bit grid
@@ -154,6 +154,7 @@ struct RebuildParams {
     const uint64_t* __restrict__ super_base;
     float4* __restrict__ out_xyzl;
     uint64_t* __restrict__ counts;
+    uint32_t skip_slab;                      // tiles of this slab are not rebuilt (the caller scatters its own records); ~0u: none
 };
 
 struct TraceParams {
@@ -161,7 +162,7 @@ struct TraceParams {
     const float4* tris;
     const uint32_t* slot_prim;
     const uint32_t* slot_label;
-    const float* slot_box;     // LRC_EDGE_TRIS: per slot lo xyz, hi xyz of the triangle's vertices
+    const float* slot_box;     // per slot lo xyz, hi xyz of the triangle's vertices
     const float4* prim_plane;  // per caller's triangle row: (v0, label bits), (Ng, 0)
     uint32_t num_nodes;
     const uint4* nodes_q;      // QN kernels: 32-byte quantised nodes (per-lane fetches) ...
@@ -227,7 +228,7 @@ __device__ __forceinline__ void rebuild_tiles(const RebuildParams& q, uint32_t t
             seg[k] = tile / q.tps;
             const uint32_t chunk = tile - seg[k] * q.tps, sb = seg[k] / q.pps;
             idx[k] = chunk * 64u + lane;
-            if (idx[k] < q.seg_len)     // read once: streaming load
+            if (idx[k] < q.seg_len && sb != q.skip_slab)     // read once: streaming load
                 prim[k] = __builtin_nontemporal_load(q.prims + (uint64_t)sb * q.stride +
                                                      (uint64_t)(seg[k] - sb * q.pps) * q.seg_len + idx[k]);
         }
@@ -380,7 +381,7 @@ template <int I> struct IntTag { static constexpr int value = I; };
 //     four-wide collapse (64-byte nodes, half the steps); a wave with a ray outside the bound the quantisation margin is
 //     proven for walks the float32 world-space nodes instead
 template <int GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false, int QN = 0>
-__global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && (LEAFW == 1 || LRC_LEAFW2_WAVES == 8)) ? 8 : 1) void trace_kernel(const TraceParams p) {
+__global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) void trace_kernel(const TraceParams p) {
     extern __shared__ int s_stack[];   // [stack depth][kTBlock]: one column per lane, conflict free
     const uint32_t tid = threadIdx.x;
     const uint64_t gid = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * kTBlock + tid;
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && (LEAFW =
     auto traverse = [&](auto qtag, auto ctag) {
         constexpr int QM = decltype(qtag)::value;
         constexpr bool Q = QM != 0;
-        constexpr bool INLINE_CLAUSE = decltype(ctag)::value != 0;    // LRC_EDGE_TRIS: the redo route tests the clause per test
+        constexpr bool INLINE_CLAUSE = decltype(ctag)::value != 0;    // the redo route tests the clause per test
         (void)INLINE_CLAUSE;
         RaySlab sl;
         uint32_t sel_nx = 0, sel_ny = 0, sel_nz = 0, sel_fx = 0, sel_fy = 0, sel_fz = 0;
@@ -591,11 +592,10 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && (LEAFW =
                         const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
                         float t;
                         bool hit;
-#ifdef LRC_EDGE_TRIS
                         // edge records (v0, e1, e2, Ng): v1 / v2 above ARE e1 / e2.  Candidates are ranked by the
                         // Moeller-Trumbore conditions on every node image; the box clause is tested once, after the
                         // traversal (below), and inline only on the redo route (INLINE_CLAUSE, float32 nodes).
-                        hit = tri_mt_e(o, d, v0, v1, v2, ng, t);
+                        hit = tri_mt(o, d, v0, v1, v2, ng, t);
                         if (INLINE_CLAUSE) {
                             if (hit) {
                                 const float* bx = p.slot_box + (size_t)slot * 6;
@@ -603,18 +603,6 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && (LEAFW =
                                 if (STATS) { if (!hit) st_pad += 1u; }
                             }
                         }
-#else
-                        if (Q) {
-                            // Candidates are ranked by the Moeller-Trumbore conditions alone; the definition's box
-                            // clause (world coordinates) is tested once, after the traversal, on the closest candidate.
-                            // If that candidate passes, it is the definition's closest hit: every triangle passing both
-                            // tests is a candidate too, and pruning by a candidate's t never hides a closer one.  If it
-                            // fails -- never observed -- the ray is redone on the float32 nodes with the clause inline.
-                            hit = tri_mt(o, d, v0, v1, v2, ng, t);
-                        } else {
-                            hit = tri_hit<STATS>(o, d, sl, v0, v1, v2, ng, t, &st_pad);
-                        }
-#endif
                         if (hit) {
                             if (t < tbest) {
                                 tbest = t; best_slot = slot; best_prim = 0xFFFFFFFFu;
@@ -687,7 +675,6 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && (LEAFW =
             --sp;
             ref = s_stack[sp * kTBlock + tid];
         }
-#ifdef LRC_EDGE_TRIS
         if (!INLINE_CLAUSE) {
             if (best_slot != 0xFFFFFFFFu) {       // the box clause of the closest candidate, in world coordinates
                 const float* bx = p.slot_box + (size_t)best_slot * 6;
@@ -705,31 +692,8 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1 && (LEAFW =
             if (p.force_redo) redo |= (gid % p.force_redo) == 0;      // test hook (LRC_DEBUG_FORCE_REDO=m)
 #endif
         }
-#else
-        if (Q) {
-            if (best_slot != 0xFFFFFFFFu) {       // the box clause of the closest candidate, in world coordinates
-                const float4* tr = p.tris + (size_t)best_slot * 3;
-                const float4 a = tr[0], b = tr[1], c = tr[2];
-                const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x};
-                RaySlab w;      // ix = ix' / W exactly (W a power of two); ox = o * ix as make_slab forms it
-                w.ix = sl.ix * p.qinvW[0]; w.iy = sl.iy * p.qinvW[1]; w.iz = sl.iz * p.qinvW[2];
-                w.ox = o.x * w.ix; w.oy = o.y * w.iy; w.oz = o.z * w.iz;
-                if (!tri_clause(w, v0, v1, v2, tbest)) {
-                    redo = true;
-                    if (STATS) st_pad += 1u;
-                }
-            }
-#ifdef LRC_VARIANTS
-            if (p.force_redo) redo |= (gid % p.force_redo) == 0;      // test hook (LRC_DEBUG_FORCE_REDO=m)
-#endif
-        }
-#endif
     };
-#ifdef LRC_EDGE_TRIS
     using FirstPass = IntTag<0>;      // edge records: every first pass defers the box clause
-#else
-    using FirstPass = IntTag<1>;      // vertex records: the float32 nodes test the clause per triangle (tri_hit)
-#endif
     if (p.num_nodes) {
         if (QN) {
             // outside this bound the margin of the quantised boxes is not proven to cover the difference
@@ -880,9 +844,9 @@ __global__ __launch_bounds__(kTBlock, W) void trace_refill_kernel(const TracePar
             const uint32_t slot = first + j;
             const float4* tr = p.tris + (size_t)slot * 3;
             const float4 a = tr[0], b = tr[1], c = tr[2];
-            const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
+            const V3 v0{a.x, a.y, a.z}, e1{a.w, b.x, b.y}, e2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
             float t;
-            if (tri_hit(o, d, sl, v0, v1, v2, ng, t)) {
+            if (tri_hit(o, d, sl, v0, e1, e2, ng, p.slot_box + (size_t)slot * 6, t)) {
                 if (t < tbest) {
                     tbest = t; best_slot = slot; best_prim = 0xFFFFFFFFu;
                 } else if (t == tbest) {
@@ -1007,11 +971,13 @@ __global__ __launch_bounds__(1024) void compact_base_kernel(const uint32_t* supe
 }
 
 // Pass B: scatter the kept entries; the first workgroups also write the per-segment counts.
+// tile_base: index of this call's tile 0 in tile_off / super_base (non-zero when the offsets come from a scan over the
+// tiles of several ranks and this call scatters one rank's records into the assembled cloud).
 __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const lrc_compact_io io,
                                                                  uint64_t seg_len, uint64_t tps,
                                                                  uint64_t ntiles, uint64_t nseg,
                                                                  const uint32_t* tile_off,
-                                                                 const uint64_t* super_base) {
+                                                                 const uint64_t* super_base, uint64_t tile_base) {
     const uint32_t lane = threadIdx.x & 63u;
     if (io.counts) {
         // one thread per segment: count = global offset of its end tile - global offset of its first tile
@@ -1033,7 +999,8 @@ __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const lrc_compa
     if (i < seg_len) keep = io.t[src] < __builtin_inff();
     const unsigned long long m = __ballot(keep);
     if (!keep) return;
-    const uint64_t tbase = super_base[tile >> 10] + tile_off[tile];
+    const uint64_t gt = tile_base + tile;
+    const uint64_t tbase = super_base[gt >> 10] + tile_off[gt];
     const uint64_t dst = tbase + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
     if (io.out_xyzl) {
         const float* sp = io.point3 + src * 3;
@@ -1056,6 +1023,15 @@ __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const lrc_compa
         const float* sp = io.point3 + src * 3;
         io.out_range_origin[dst] = __builtin_sqrtf((sp[0] * sp[0] + sp[1] * sp[1]) + sp[2] * sp[2]);
     }
+}
+
+// |p| of assembled (x, y, z, label) rows from the WORLD origin, float32, as np.linalg.norm(points, axis=1) forms it
+// (the quantity the reference's ScanQuality range statistics are taken over, s3dis_simulator.py:283-284)
+__global__ __launch_bounds__(kBlock) void rows_range_kernel(const float4* __restrict__ rows, uint64_t n, float* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 r = rows[i];
+    out[i] = __builtin_sqrtf((r.x * r.x + r.y * r.y) + r.z * r.z);
 }
 
 // ---- scene cloud from per-ray (t, label) pairs -------------------------------------------------------
@@ -1156,24 +1132,19 @@ __global__ __launch_bounds__(kBlock) void prim_scatter_kernel(const RebuildParam
 #ifdef LRC_VARIANTS
 // Bounding sphere of every triangle's axis-aligned box (centre and half diagonal, rounded up): what sector_kernel
 // tests against a packet of rays before it runs the exact ray/triangle test.  Built on first use of the packet kernel.
-__global__ __launch_bounds__(kBlock) void slot_sphere_kernel(const float4* __restrict__ tris, uint32_t num_slots,
+__global__ __launch_bounds__(kBlock) void slot_sphere_kernel(const float* __restrict__ slot_box, uint32_t num_slots,
                                                              float4* __restrict__ sphere) {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= num_slots) return;
-    const float4 a = tris[(size_t)k * 3], b = tris[(size_t)k * 3 + 1], c = tris[(size_t)k * 3 + 2];
-    const float v[3][3] = {{a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}};
+    const float* bx = slot_box + (size_t)k * 6;
     float ctr[3];
-    double lo[3], hi[3], hd2 = 0.0;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        lo[q] = fmin(fmin((double)v[0][q], (double)v[1][q]), (double)v[2][q]);
-        hi[q] = fmax(fmax((double)v[0][q], (double)v[1][q]), (double)v[2][q]);
-        ctr[q] = (float)(0.5 * (lo[q] + hi[q]));
-    }
+    double hd2 = 0.0;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {       // distance from the ROUNDED centre to the farthest corner
+        const double lo = (double)bx[q], hi = (double)bx[3 + q];
+        ctr[q] = (float)(0.5 * (lo + hi));
         const double cc = (double)ctr[q];
-        const double e = fmax(hi[q] - cc, cc - lo[q]);
+        const double e = fmax(hi - cc, cc - lo);
         hd2 += e * e;
     }
     const float r = (float)__builtin_sqrt(hd2);
@@ -1581,7 +1552,7 @@ int lrc_scene_export_array(const lrc_scene* cs, int which, void* dst, uint64_t d
 static int launch_trace_lab(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, bool stats, uint64_t nblk, size_t lds,
                             uint32_t depth) {
     static const int force_redo = env_int("LRC_DEBUG_FORCE_REDO", 0);
-    static const int leafw = env_int("LRC_LEAFW", 1), uni = env_int("LRC_UNIFORM", 1), spec = env_int("LRC_SPEC", 0);
+    static const int leafw = env_int("LRC_LEAFW", kLeafW) == 1 ? 1 : 2, uni = env_int("LRC_UNIFORM", 1), spec = env_int("LRC_SPEC", 0);
     static const int sector = env_int("LRC_SECTOR", 1), refill = env_int("LRC_REFILL", 0);
     p.force_redo = (uint32_t)force_redo;
     const bool qn = s->d_nodes_q != nullptr, wide = s->d_nodes_q4 != nullptr;
@@ -1591,8 +1562,7 @@ static int launch_trace_lab(lrc_scene* s, TraceParams& p, int gen, hipStream_t s
     do {                                                                                             \
         if (spec) { if (leafw == 2) LRC_LAB(G, 2, true, true, 0); else LRC_LAB(G, 1, true, true, 0); } \
         else if (!uni) { if (leafw == 2) LRC_LAB(G, 2, false, false, 0); else LRC_LAB(G, 1, false, false, 0); } \
-        else if (leafw == 2) { if (qn) LRC_LAB(G, 2, true, false, 1); else LRC_LAB(G, 2, true, false, 0); }  \
-        else LRC_LAB(G, 1, true, false, 0);        /* not reached: the plain case is the product dispatch */ \
+        else { if (qn) LRC_LAB(G, 1, true, false, 1); else LRC_LAB(G, 1, true, false, 0); }     /* leafw == 1 */ \
     } while (0)
     if (gen == 3 && sector && !stats) {
         const lrc_grid& g = *s->cur_grid;
@@ -1604,7 +1574,7 @@ static int launch_trace_lab(lrc_scene* s, TraceParams& p, int gen, hipStream_t s
             LRC_HIP(hipMalloc((void**)&s->d_slot_sphere, s->info.num_slots * 16));
             s->info.device_bytes += s->info.num_slots * 16;
             hipLaunchKernelGGL(slot_sphere_kernel, dim3((uint32_t)((s->info.num_slots + kBlock - 1) / kBlock)), dim3(kBlock),
-                               0, st, (const float4*)s->d_tris, (uint32_t)s->info.num_slots, s->d_slot_sphere);
+                               0, st, (const float*)s->d_slot_box, (uint32_t)s->info.num_slots, s->d_slot_sphere);
         }
         q.slot_sphere = s->d_slot_sphere;
         q.H = g.lines; q.W = g.width;
@@ -1654,13 +1624,14 @@ static int launch_trace_lab(lrc_scene* s, TraceParams& p, int gen, hipStream_t s
         return LRC_OK;
     }
     if (stats) {
-        if (gen == 1 && qn && wide) { hipLaunchKernelGGL((trace_kernel<1, 1, true, false, true, 2>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p); return LRC_OK; }
+        if (gen == 1 && qn && wide) { hipLaunchKernelGGL((trace_kernel<1, kLeafW, true, false, true, 2>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p); return LRC_OK; }
         return 1;
     }
-    const bool plain = leafw != 2 && uni && !spec && !(qn && wide);
+    const bool plain = leafw == kLeafW && uni && !spec && !(qn && wide);
     if (plain || gen == 2) return 1;
-    if (gen == 1) { if (qn && wide && leafw != 2 && uni && !spec) LRC_LAB(1, 1, true, false, 2); else LRC_LAB_PICK(1); }
-    else { if (qn && wide && leafw != 2 && uni && !spec) LRC_LAB(0, 1, true, false, 2); else LRC_LAB_PICK(0); }
+    const bool wide_only = qn && wide && leafw == kLeafW && uni && !spec;
+    if (gen == 1) { if (wide_only) LRC_LAB(1, kLeafW, true, false, 2); else LRC_LAB_PICK(1); }
+    else { if (wide_only) LRC_LAB(0, kLeafW, true, false, 2); else LRC_LAB_PICK(0); }
 #undef LRC_LAB_PICK
 #undef LRC_LAB
     return LRC_OK;
@@ -1708,7 +1679,7 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
 #endif
     if (gen == 3) gen = 1;
 #define LRC_LAUNCH(G, S, Q) \
-    hipLaunchKernelGGL((trace_kernel<G, 1, true, false, S, Q>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p)
+    hipLaunchKernelGGL((trace_kernel<G, kLeafW, true, false, S, Q>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p)
     if (stats) {   // per-ray traversal counters (lrc_debug_scan_stats)
         if (gen == 1) { if (qn) LRC_LAUNCH(1, true, 1); else LRC_LAUNCH(1, true, 0); }
         else if (gen == 0) { if (qn) LRC_LAUNCH(0, true, 1); else LRC_LAUNCH(0, true, 0); }
@@ -1731,11 +1702,11 @@ int lrc_scene_get_occupancy(const lrc_scene* s, int* waves_per_cu, int* vgprs, i
     int blocks = 0;
     hipFuncAttributes attr;
     if (s->d_nodes_q) {
-        LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<1, 1, true, false, false, 1>, kTBlock, lds));
-        LRC_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trace_kernel<1, 1, true, false, false, 1>)));
+        LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<1, kLeafW, true, false, false, 1>, kTBlock, lds));
+        LRC_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trace_kernel<1, kLeafW, true, false, false, 1>)));
     } else {
-        LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<1, 1, true, false, false>, kTBlock, lds));
-        LRC_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trace_kernel<1, 1, true, false, false>)));
+        LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<1, kLeafW, true, false, false>, kTBlock, lds));
+        LRC_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trace_kernel<1, kLeafW, true, false, false>)));
     }
     if (waves_per_cu) *waves_per_cu = blocks * (kTBlock / 64);
     if (vgprs) *vgprs = attr.numRegs;
@@ -2010,7 +1981,7 @@ int lrc_compact_dev(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_com
     const uint64_t need = io->counts ? (nseg + kBlock - 1) / kBlock : 0;
     const uint64_t grid = nblocks > need ? nblocks : need;
     hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, st, *io, seg_len, tps,
-                       ntiles, nseg, (const uint32_t*)sc.d_tile_off, (const uint64_t*)sc.d_super_base);
+                       ntiles, nseg, (const uint32_t*)sc.d_tile_off, (const uint64_t*)sc.d_super_base, (uint64_t)0);
     LRC_HIP(hipGetLastError());
     return LRC_OK;
 }
@@ -2123,6 +2094,7 @@ static int prepare_rebuild(lrc_scene* s, const char* who, const double* d_poses1
     q->super_base = sc.d_super_base;
     q->out_xyzl = (float4*)d_out_xyzl;
     q->counts = d_counts;
+    q->skip_slab = 0xFFFFFFFFu;
     return LRC_OK;
 }
 
@@ -2140,6 +2112,60 @@ int lrc_cloud_from_prims_dev(lrc_scene* s, const double* d_poses16, uint64_t P, 
     constexpr int kR = LRC_REBUILD_R;
     const uint64_t wblocks = (((uint64_t)q.ntiles + kR - 1) / kR + kBlock / 64 - 1) / (kBlock / 64);
     hipLaunchKernelGGL(prim_scatter_kernel<kR>, dim3((uint32_t)(wblocks ? wblocks : 1)), dim3(kBlock), 0, st, q);
+    LRC_HIP(hipGetLastError());
+    return LRC_OK;
+}
+
+int lrc_cloud_from_prims_own_dev(lrc_scene* s, const double* d_poses16, uint64_t P, const double* d_dirs3, uint64_t N,
+                                 const uint32_t* d_prim, const uint32_t* d_tile_count, uint64_t poses_per_slab,
+                                 uint64_t slab_stride_bytes, uint64_t own_slab, const lrc_compact_io* own,
+                                 float* d_out_xyzl, uint64_t* d_counts, void* stream) {
+    if (!s) return fail(LRC_ERR_INVALID_ARG, "lrc_cloud_from_prims_own_dev: scene is NULL");
+    if (P == 0 || N == 0) return LRC_OK;
+    if (!own || !own->t || !own->point3)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_cloud_from_prims_own_dev: the own records need t and point3");
+    if (!d_tile_count || N % 64 || poses_per_slab == 0 || poses_per_slab > P || own_slab * poses_per_slab >= P)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_cloud_from_prims_own_dev: needs per-wave keep counts (rays_per_pose % 64 == 0), "
+                                         "slabs and an own slab inside the scan");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    RebuildParams q{};
+    int rc = prepare_rebuild(s, "lrc_cloud_from_prims_own_dev", d_poses16, P, d_dirs3, N, d_prim, d_tile_count,
+                             poses_per_slab, slab_stride_bytes, d_out_xyzl, d_counts, st, &q);
+    if (rc) return rc;
+    q.skip_slab = (uint32_t)own_slab;
+    constexpr int kR = LRC_REBUILD_R;
+    const uint64_t wblocks = (((uint64_t)q.ntiles + kR - 1) / kR + kBlock / 64 - 1) / (kBlock / 64);
+    hipLaunchKernelGGL(prim_scatter_kernel<kR>, dim3((uint32_t)(wblocks ? wblocks : 1)), dim3(kBlock), 0, st, q);
+    // the own poses: rows straight from the local record (what the trace wrote), at the offsets of the assembled cloud
+    const uint64_t first_pose = own_slab * poses_per_slab;
+    const uint64_t own_poses = first_pose + poses_per_slab <= P ? poses_per_slab : P - first_pose;
+    const uint64_t tps = N / 64, own_tiles = own_poses * tps;
+    lrc_compact_io io = *own;
+    io.counts = nullptr;                 // the per-pose counts of ALL poses come from the rebuild's scan
+    io.out_point3 = nullptr; io.out_sem = nullptr; io.out_ins = nullptr; io.out_incident_deg = nullptr;
+    io.out_index = nullptr; io.out_range_origin = nullptr;
+    io.out_xyzl = d_out_xyzl;
+    const uint64_t nblocks = (own_tiles + kBlock / 64 - 1) / (kBlock / 64);
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, io, N, tps, own_tiles, own_poses,
+                       (const uint32_t*)q.tile_off, (const uint64_t*)q.super_base, first_pose * tps);
+    LRC_HIP(hipGetLastError());
+    return LRC_OK;
+}
+
+int lrc_cloud_range_stats_dev(lrc_ctx* ctx, const float* d_xyzl, const uint64_t* d_counts, uint64_t num_poses,
+                              uint64_t max_rows, float* d_range, float* d_mean, float* d_std, void* stream) {
+    if (!ctx) return fail(LRC_ERR_INVALID_ARG, "lrc_cloud_range_stats_dev: ctx is NULL");
+    if (num_poses == 0) return LRC_OK;
+    if (!d_xyzl || !d_counts || !d_range || !d_mean || !d_std)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_cloud_range_stats_dev: NULL argument");
+    LRC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (max_rows)
+        hipLaunchKernelGGL(rows_range_kernel, dim3((uint32_t)((max_rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           (const float4*)d_xyzl, max_rows, d_range);
+    hipLaunchKernelGGL(segment_stats_kernel<float>, dim3((uint32_t)num_poses), dim3(256), 0, st, (const float*)d_range,
+                       d_counts, (uint64_t)0, num_poses, d_mean, d_std);
     LRC_HIP(hipGetLastError());
     return LRC_OK;
 }

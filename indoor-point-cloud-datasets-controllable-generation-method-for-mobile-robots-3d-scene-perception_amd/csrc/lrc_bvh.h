@@ -25,7 +25,7 @@ struct HostBVH {
     std::vector<float>    tri_rec;     // 12 floats per slot
     std::vector<uint32_t> slot_prim;
     std::vector<uint32_t> slot_label;
-    std::vector<float>    slot_box;    // LRC_EDGE_TRIS: 6 floats per slot, the triangle's exact vertex box (lo xyz, hi xyz)
+    std::vector<float>    slot_box;    // 6 floats per slot, the triangle's exact vertex box (lo xyz, hi xyz)
     uint64_t num_nodes = 0, num_leaves = 0, num_slots = 0;
     uint32_t max_depth = 0, max_leaf_size = 0;
     float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};

@@ -32,7 +32,7 @@ struct DeviceScene {               // one allocation (`slab`), the arrays point 
     void* tris = nullptr;          // (num_slots + 3) x 48 B
     uint32_t* slot_prim = nullptr;
     uint32_t* slot_label = nullptr;
-    float* slot_box = nullptr;     // LRC_EDGE_TRIS: num_slots x 24 B
+    float* slot_box = nullptr;     // num_slots x 24 B
     void* nodes_q = nullptr;       // num_nodes x 32 B, or NULL
     void* nodes_n = nullptr;       // num_nodes x 64 B, or NULL
     uint64_t num_nodes = 0, num_leaves = 0, num_slots = 0;

@@ -978,7 +978,6 @@ __global__ __launch_bounds__(256) void k_tri_records(const float* verts3, const 
     const float nx = __builtin_fmaf(e2[1], e1[2], -(e2[2] * e1[1]));
     const float ny = __builtin_fmaf(e2[2], e1[0], -(e2[0] * e1[2]));
     const float nz = __builtin_fmaf(e2[0], e1[1], -(e2[1] * e1[0]));
-#ifdef LRC_EDGE_TRIS
     o[0] = make_float4(a[0], a[1], a[2], e1[0]);
     o[1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
     o[2] = make_float4(e2[2], nx, ny, nz);
@@ -987,12 +986,6 @@ __global__ __launch_bounds__(256) void k_tri_records(const float* verts3, const 
         slot_box[(size_t)s * 6 + k] = dec(imin(imin(enc(a[k]), enc(b[k])), enc(c[k])));
         slot_box[(size_t)s * 6 + 3 + k] = dec(imax(imax(enc(a[k]), enc(b[k])), enc(c[k])));
     }
-#else
-    (void)slot_box;
-    o[0] = make_float4(a[0], a[1], a[2], b[0]);
-    o[1] = make_float4(b[1], b[2], c[0], c[1]);
-    o[2] = make_float4(c[2], nx, ny, nz);
-#endif
     const uint32_t lab = (sem ? (uint32_t)sem[id] : 0u) | ((ins ? (uint32_t)ins[id] : 0u) << 16);
     slot_prim[s] = id;
     slot_label[s] = lab;
@@ -1235,11 +1228,7 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_nodes = al((size_t)nn * 64), b_q = qg.enabled ? al((size_t)nn * 32) : 0, b_n = qg.enabled ? al((size_t)nn * 64) : 0;
     const size_t b_tris = al(((size_t)T + 3) * 48), b_id = al((size_t)T * 4);
-#ifdef LRC_EDGE_TRIS
     const size_t b_box = al((size_t)T * 24);
-#else
-    const size_t b_box = 0;
-#endif
     const size_t slab_bytes = b_nodes + b_q + b_n + b_tris + 2 * b_id + b_box;
     void* slab = nullptr;
     DB_HIP(hipMalloc(&slab, slab_bytes));

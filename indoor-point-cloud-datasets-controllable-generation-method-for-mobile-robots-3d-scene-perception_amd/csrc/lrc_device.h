@@ -77,46 +77,17 @@ LRC_DI void slab_interval(const RaySlab& s, float lox, float loy, float loz, flo
     tf = fma_(f, kPadRelHi, kPadAbs);
 }
 
-// Ray/triangle test.  Returns true and t when (o,d) hits the triangle record (v0,v1,v2,Ng):
+// Ray/triangle test on an edge record (v0, e1 = v0 - v1, e2 = v2 - v0, Ng = cross(e2, e1)); the hit definition of
+// DESIGN.md section 3 is tri_mt && box_clause:
 //   den = Ng.D != 0,  U = (C x D).e2,  V = (C x D).e1 (sign-corrected), U,V >= 0, U+V <= |den|,
-//   T = Ng.C (sign-corrected) > 0,  t = T/|den| finite and inside the padded slab interval of the
-//   triangle's own bounding box.
-// DIAG builds (lrc_debug_scan_stats) count in pad_rej the triangles that pass every Moeller-Trumbore condition and are
-// rejected by the box clause alone -- the one clause Embree does not have; the product build compiles the counter away.
-template <bool DIAG = false>
-LRC_DI bool tri_hit(V3 o, V3 d, const RaySlab& s, V3 v0, V3 v1, V3 v2, V3 ng, float& t_out, uint32_t* pad_rej = nullptr) {
-    V3 e1 = sub3(v0, v1);
-    V3 e2 = sub3(v2, v0);
-    V3 c = sub3(v0, o);
-    V3 r = cross3(c, d);
-    float den = dot3(ng, d);
-    float aden = __builtin_fabsf(den);
-    uint32_t sgn = __float_as_uint(den) & 0x80000000u;
-    float u = xorsign(dot3(r, e2), sgn);
-    float v = xorsign(dot3(r, e1), sgn);
-    float tt = xorsign(dot3(ng, c), sgn);
-    bool ok = (den != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= aden) & (tt > 0.0f);
-    if (!ok) return false;
-    float t = tt / aden;
-    float lox = min2(min2(v0.x, v1.x), v2.x), hix = max2(max2(v0.x, v1.x), v2.x);
-    float loy = min2(min2(v0.y, v1.y), v2.y), hiy = max2(max2(v0.y, v1.y), v2.y);
-    float loz = min2(min2(v0.z, v1.z), v2.z), hiz = max2(max2(v0.z, v1.z), v2.z);
-    float tn, tf;
-    slab_interval(s, lox, loy, loz, hix, hiy, hiz, tn, tf);
-    if (!((tn <= t) & (t <= tf) & (t < __builtin_inff()))) {
-        if (DIAG) { if (t < __builtin_inff()) *pad_rej += 1u; }
-        return false;
-    }
-    t_out = t;
-    return true;
-}
-
-// The two halves of tri_hit, for callers that test the box clause once, for the closest candidate only (trace_kernel on the
-// quantised nodes): tri_mt = the Moeller-Trumbore conditions and t (finite), tri_clause = the padded box interval of the
-// triangle.  tri_mt && tri_clause is tri_hit, expression for expression.
-LRC_DI bool tri_mt(V3 o, V3 d, V3 v0, V3 v1, V3 v2, V3 ng, float& t_out) {
-    V3 e1 = sub3(v0, v1);
-    V3 e2 = sub3(v2, v0);
+//   T = Ng.C (sign-corrected) > 0,  t = T/|den| finite  [tri_mt: the Moeller-Trumbore conditions, Embree's form]
+//   and t inside the padded slab interval of the triangle's own vertex box  [box_clause: the one clause Embree lacks]
+// The traversal ranks candidates by tri_mt alone and tests the clause ONCE, on the closest candidate, after the
+// traversal: if it passes, that candidate is the definition's closest hit (every triangle passing both tests is a
+// candidate too, and pruning by a candidate's t never hides a closer one); if it fails -- never observed -- the ray is
+// redone with the clause tested per triangle.  The edges are stored, not formed per test: six subtractions and seven
+// registers less in the hot loop; the vertex box the clause needs sits in a side table (slot_box).
+LRC_DI bool tri_mt(V3 o, V3 d, V3 v0, V3 e1, V3 e2, V3 ng, float& t_out) {
     V3 c = sub3(v0, o);
     V3 r = cross3(c, d);
     float den = dot3(ng, d);
@@ -132,62 +103,16 @@ LRC_DI bool tri_mt(V3 o, V3 d, V3 v0, V3 v1, V3 v2, V3 ng, float& t_out) {
     t_out = t;
     return true;
 }
-// tri_mt on an edge record (v0, e1 = v0 - v1, e2 = v2 - v0, Ng): the same expressions without the six subtractions
-LRC_DI bool tri_mt_e(V3 o, V3 d, V3 v0, V3 e1, V3 e2, V3 ng, float& t_out) {
-    V3 c = sub3(v0, o);
-    V3 r = cross3(c, d);
-    float den = dot3(ng, d);
-    float aden = __builtin_fabsf(den);
-    uint32_t sgn = __float_as_uint(den) & 0x80000000u;
-    float u = xorsign(dot3(r, e2), sgn);
-    float v = xorsign(dot3(r, e1), sgn);
-    float tt = xorsign(dot3(ng, c), sgn);
-    bool ok = (den != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= aden) & (tt > 0.0f);
-    if (!ok) return false;
-    float t = tt / aden;
-    if (!(t < __builtin_inff())) return false;
-    t_out = t;
-    return true;
-}
-// the box clause on a stored vertex box
 LRC_DI bool box_clause(const RaySlab& s, float lox, float loy, float loz, float hix, float hiy, float hiz, float t) {
     float tn, tf;
     slab_interval(s, lox, loy, loz, hix, hiy, hiz, tn, tf);
     return (tn <= t) & (t <= tf);
 }
-LRC_DI bool tri_clause(const RaySlab& s, V3 v0, V3 v1, V3 v2, float t) {
-    float lox = min2(min2(v0.x, v1.x), v2.x), hix = max2(max2(v0.x, v1.x), v2.x);
-    float loy = min2(min2(v0.y, v1.y), v2.y), hiy = max2(max2(v0.y, v1.y), v2.y);
-    float loz = min2(min2(v0.z, v1.z), v2.z), hiz = max2(max2(v0.z, v1.z), v2.z);
-    float tn, tf;
-    slab_interval(s, lox, loy, loz, hix, hiy, hiz, tn, tf);
-    return (tn <= t) & (t <= tf);
-}
-
-// tri_hit for callers that have no RaySlab at hand (sector_kernel tests a few rays against one triangle): identical
-// conditions and arithmetic; the ray's slab constants are formed only for the rare pair that passes the
-// Moeller-Trumbore conditions, which is when the box clause needs them.
-LRC_DI bool tri_hit_lazy(V3 o, V3 d, V3 v0, V3 v1, V3 v2, V3 ng, float& t_out) {
-    V3 e1 = sub3(v0, v1);
-    V3 e2 = sub3(v2, v0);
-    V3 c = sub3(v0, o);
-    V3 r = cross3(c, d);
-    float den = dot3(ng, d);
-    float aden = __builtin_fabsf(den);
-    uint32_t sgn = __float_as_uint(den) & 0x80000000u;
-    float u = xorsign(dot3(r, e2), sgn);
-    float v = xorsign(dot3(r, e1), sgn);
-    float tt = xorsign(dot3(ng, c), sgn);
-    bool ok = (den != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= aden) & (tt > 0.0f);
-    if (!ok) return false;
-    float t = tt / aden;
-    const RaySlab s = make_slab(o, d);
-    float lox = min2(min2(v0.x, v1.x), v2.x), hix = max2(max2(v0.x, v1.x), v2.x);
-    float loy = min2(min2(v0.y, v1.y), v2.y), hiy = max2(max2(v0.y, v1.y), v2.y);
-    float loz = min2(min2(v0.z, v1.z), v2.z), hiz = max2(max2(v0.z, v1.z), v2.z);
-    float tn, tf;
-    slab_interval(s, lox, loy, loz, hix, hiy, hiz, tn, tf);
-    if (!((tn <= t) & (t <= tf) & (t < __builtin_inff()))) return false;
+// both at once, for callers that test few (ray, triangle) pairs (laboratory kernels): bx = the slot's box, 6 floats
+LRC_DI bool tri_hit(V3 o, V3 d, const RaySlab& s, V3 v0, V3 e1, V3 e2, V3 ng, const float* bx, float& t_out) {
+    float t;
+    if (!tri_mt(o, d, v0, e1, e2, ng, t)) return false;
+    if (!box_clause(s, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], t)) return false;
     t_out = t;
     return true;
 }

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64) void sector_kernel(const SectorParams q) {
             const uint32_t il_lo = pr.lo_hi_mask & 0xFFu, il_hi = (pr.lo_hi_mask >> 8) & 0xFFu, lmask = pr.lo_hi_mask >> 16;
             const float4* tr = p.tris + (size_t)slot * 3;
             const float4 a = tr[0], b = tr[1], c = tr[2];
-            const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
+            const V3 v0{a.x, a.y, a.z}, e1{a.w, b.x, b.y}, e2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
             uint32_t prim = 0xFFFFFFFFu;
             for (uint32_t jl = 0; jl < nlines; ++jl) {
                 if (!((lmask >> jl) & 1u)) continue;
@@ -198,7 +198,11 @@ __global__ __launch_bounds__(64) void sector_kernel(const SectorParams q) {
                     if (!finite_ray(o, d)) continue;
                     float t;
                     if (DIAG) dg[6] += 1;
-                    if (tri_hit_lazy(o, d, v0, v1, v2, ng, t)) {
+                    // the few pairs that pass the Moeller-Trumbore conditions form the ray's slab constants for the clause
+                    if (tri_mt(o, d, v0, e1, e2, ng, t) &&
+                        box_clause(make_slab(o, d), p.slot_box[(size_t)slot * 6], p.slot_box[(size_t)slot * 6 + 1],
+                                   p.slot_box[(size_t)slot * 6 + 2], p.slot_box[(size_t)slot * 6 + 3],
+                                   p.slot_box[(size_t)slot * 6 + 4], p.slot_box[(size_t)slot * 6 + 5], t)) {
                         if (DIAG) dg[7] += 1;
                         if (prim == 0xFFFFFFFFu) prim = p.slot_prim[slot];
                         const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | prim;

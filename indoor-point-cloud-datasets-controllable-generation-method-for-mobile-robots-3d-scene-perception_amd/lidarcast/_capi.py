@@ -31,6 +31,7 @@ SYMBOLS = (
     "lrc_scan_grid_dev", "lrc_scan_grid_compact", "lrc_scan_rays_compact",
     "lrc_table_create", "lrc_table_destroy", "lrc_scan_table_compact",
     "lrc_compact", "lrc_compact_dev", "lrc_cloud_from_ranges_dev", "lrc_cloud_from_prims_dev",
+    "lrc_cloud_from_prims_own_dev", "lrc_cloud_range_stats_dev",
     "lrc_nn_create", "lrc_nn_destroy", "lrc_nn_query", "lrc_nn_query_dev",
     "lrc_min_distances", "lrc_rbf_kernel_sum",
     "lrc_occ_create", "lrc_occ_destroy", "lrc_occ_query",
@@ -149,6 +150,8 @@ def load():
         "lrc_nn_query_dev": [vp, vp, u64, vp, vp, vp],
         "lrc_cloud_from_ranges_dev": [vp, vp, u64, vp, u64, vp, vp, vp, vp],
         "lrc_cloud_from_prims_dev": [vp, vp, u64, vp, u64, vp, vp, u64, u64, vp, vp, vp],
+        "lrc_cloud_from_prims_own_dev": [vp, vp, u64, vp, u64, vp, vp, u64, u64, u64, C.POINTER(LrcCompactIO), vp, vp, vp],
+        "lrc_cloud_range_stats_dev": [vp, vp, vp, u64, u64, vp, vp, vp, vp],
         "lrc_compact": [vp, u64, u64, C.POINTER(LrcCompactIO), C.POINTER(u64)],
         "lrc_compact_dev": [vp, u64, u64, C.POINTER(LrcCompactIO), vp],
         "lrc_rng_scan_draws": [C.POINTER(LrcMt19937State), u64, u64, u64, dbl, dbl, vp, vp, i32],

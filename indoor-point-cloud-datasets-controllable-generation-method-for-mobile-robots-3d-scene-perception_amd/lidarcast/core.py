@@ -300,6 +300,13 @@ class Context:
             None if counts_t is None else C.c_void_p(counts_t.data_ptr()), C.c_void_p(int(stream))),
             "lrc_cloud_from_ranges_dev")
 
+    def cloud_range_stats_dev(self, rows_t, counts_t, range_t, mean_t, std_t, stream=0):
+        """Per-pose mean / std of |row| (float32, numpy's arithmetic) over assembled (x, y, z, label) rows in HBM."""
+        check(self._lib.lrc_cloud_range_stats_dev(
+            self._h, C.c_void_p(rows_t.data_ptr()), C.c_void_p(counts_t.data_ptr()), counts_t.shape[0], rows_t.shape[0],
+            C.c_void_p(range_t.data_ptr()), C.c_void_p(mean_t.data_ptr()), C.c_void_p(std_t.data_ptr()),
+            C.c_void_p(int(stream))), "lrc_cloud_range_stats_dev")
+
     def compact_dev(self, nseg, seg_len, io, stream=0):
         """io: LrcCompactIO filled with device pointers."""
         check(self._lib.lrc_compact_dev(self._h, int(nseg), int(seg_len), C.byref(io),
@@ -696,9 +703,19 @@ class Scene:
               "lrc_scan_poses_dev")
 
     def cloud_from_prims_dev(self, poses_t, dirs_t, prim_t, out_rows_t, counts_t=None, tile_count_t=None,
-                             poses_per_slab=0, slab_stride_bytes=0, stream=0):
+                             poses_per_slab=0, slab_stride_bytes=0, stream=0, own_slab=None, own_io=None):
         """Rebuild the compacted (x, y, z, label) rows of a pose-batched scan from its 4-byte triangle ids
-        (lrc_hits.prim), in place over the gathered send slabs of several ranks (lrc_cloud_from_prims_dev)."""
+        (lrc_hits.prim), in place over the gathered send slabs of several ranks (lrc_cloud_from_prims_dev).
+        ``own_slab`` + ``own_io`` (LrcCompactIO with t / point3 / sem / ins of that slab's poses): the caller's own rows
+        come from its local records instead of being rebuilt (lrc_cloud_from_prims_own_dev)."""
+        if own_slab is not None:
+            check(self._lib.lrc_cloud_from_prims_own_dev(
+                self._h, C.c_void_p(poses_t.data_ptr()), poses_t.shape[0], C.c_void_p(dirs_t.data_ptr()),
+                dirs_t.shape[0], C.c_void_p(prim_t.data_ptr()), C.c_void_p(tile_count_t.data_ptr()),
+                int(poses_per_slab), int(slab_stride_bytes), int(own_slab), C.byref(own_io),
+                C.c_void_p(out_rows_t.data_ptr()), None if counts_t is None else C.c_void_p(counts_t.data_ptr()),
+                C.c_void_p(int(stream))), "lrc_cloud_from_prims_own_dev")
+            return
         check(self._lib.lrc_cloud_from_prims_dev(
             self._h, C.c_void_p(poses_t.data_ptr()), poses_t.shape[0], C.c_void_p(dirs_t.data_ptr()),
             dirs_t.shape[0], C.c_void_p(prim_t.data_ptr()),

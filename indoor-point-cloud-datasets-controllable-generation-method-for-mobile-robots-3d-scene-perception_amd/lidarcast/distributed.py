@@ -195,7 +195,9 @@ def scan_frames_sharded(engine, intrinsics, poses, mesh, dist, group=None):
     plug in a stand-in so that sharding, gather and ordering run under gloo without a GPU):
       engine.prim_gather(poses_local, rays_per_pose, dist, group) -> PrimGather
       engine.scan_block_into(gather, intrinsics, block_poses, mesh)       trace -> ids + keep counts in the send slab
-      engine.cloud_from_gather(gather, intrinsics, padded_poses, mesh)    -> (rows (K,4) f32 numpy, counts numpy)
+      engine.cloud_from_gather(gather, intrinsics, padded_poses, mesh)    -> (rows (K,4) f32 numpy, counts numpy
+                                                                              [, {"range_origin_mean", "range_origin_std"}
+                                                                               per-pose statistics computed on the device])
     """
     poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 4, 4)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -212,13 +214,18 @@ def scan_frames_sharded(engine, intrinsics, poses, mesh, dist, group=None):
     padded = np.tile(np.eye(4), (world * per, 1, 1))
     for r in range(world):
         padded[r * per:r * per + (b[r + 1] - b[r])] = poses[b[r]:b[r + 1]]
-    rows, counts = engine.cloud_from_gather(g, intrinsics, padded, mesh)
+    res = engine.cloud_from_gather(g, intrinsics, padded, mesh)
+    rows, counts = res[0], res[1]
+    stats = res[2] if len(res) > 2 else {}
     real = np.concatenate([np.arange(r * per, r * per + (b[r + 1] - b[r])) for r in range(world)]).astype(np.int64)
     counts = np.asarray(counts, dtype=np.int64)
     assert int(counts.sum()) == int(counts[real].sum()), "a padded pose produced returns"
     lab = np.ascontiguousarray(rows[:, 3]).view(np.uint32)
-    return {"point3": np.ascontiguousarray(rows[:, :3]), "sem": (lab & 0xFFFF).astype(np.uint16),
-            "ins": (lab >> 16).astype(np.uint16), "counts": counts[real], "total": int(len(rows))}
+    out = {"point3": np.ascontiguousarray(rows[:, :3]), "sem": (lab & 0xFFFF).astype(np.uint16),
+           "ins": (lab >> 16).astype(np.uint16), "counts": counts[real], "total": int(len(rows))}
+    for k, v in stats.items():
+        out[k] = np.asarray(v)[real]
+    return out
 
 
 def scan_lidars_sharded(engine, lidars, mesh, dist, group=None, device=None):

@@ -421,11 +421,17 @@ class RaycastEngineHIP(RaycastEngineBase):
         d_dirs = torch.from_numpy(np.ascontiguousarray(dirs)).to(dev)
         rows = torch.empty((P * n, 4), dtype=torch.float32, device=dev)
         counts = torch.zeros(P, dtype=torch.int64, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
         scene.cloud_from_prims_dev(d_poses, d_dirs, g.all_prims, rows, counts, g.all_tile_counts,
-                                   poses_per_slab=g.poses_local, slab_stride_bytes=g.stride_bytes,
-                                   stream=torch.cuda.current_stream().cuda_stream)
+                                   poses_per_slab=g.poses_local, slab_stride_bytes=g.stride_bytes, stream=st)
+        # the ScanQuality range statistics of every pose, on the assembled rows, with numpy's arithmetic (lrc_stats.h)
+        rng = torch.empty(P * n, dtype=torch.float32, device=dev)
+        mean = torch.empty(P, dtype=torch.float32, device=dev)
+        std = torch.empty(P, dtype=torch.float32, device=dev)
+        self.ctx.cloud_range_stats_dev(rows, counts, rng, mean, std, stream=st)
         c = counts.cpu().numpy()
-        return rows[:int(c.sum())].cpu().numpy(), c
+        stats = {"range_origin_mean": mean.cpu().numpy(), "range_origin_std": std.cpu().numpy()}
+        return rows[:int(c.sum())].cpu().numpy(), c, stats
 
     @staticmethod
     def split_frames(frames, name):

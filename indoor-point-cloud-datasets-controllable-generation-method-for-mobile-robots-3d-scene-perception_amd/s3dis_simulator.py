@@ -230,10 +230,17 @@ class S3DISSimulator:
             else:
                 lidars = [create_lidar(self.lidar_config, wp.to_pose_matrix()) for wp in waypoints]
                 fr = scan_lidars_sharded(engine, lidars, mesh, dist, group)
-            # attributes the gathered rows do not carry are the reference's own numpy expressions of the points
-            ends = np.cumsum(fr["counts"])
-            fr["range_origin"] = np.linalg.norm(fr["point3"], axis=1) if fr["total"] else np.zeros(0, np.float32)
+            # attributes the gathered rows do not carry are the reference's own numpy expressions of the points; the
+            # range statistics come from the device when the engine computed them on the assembled rows
+            from lidarcast.npmodel import reductions_match
+            if "range_origin_mean" in fr and not reductions_match():
+                del fr["range_origin_mean"], fr["range_origin_std"]
+            if "range_origin_mean" not in fr:
+                fr["range_origin"] = np.linalg.norm(fr["point3"], axis=1) if fr["total"] else np.zeros(0, np.float32)
             if not self.bug_compatible:
+                fr.pop("range_origin_mean", None), fr.pop("range_origin_std", None)     # angle statistics: host numpy
+                if "range_origin" not in fr:
+                    fr["range_origin"] = np.linalg.norm(fr["point3"], axis=1) if fr["total"] else np.zeros(0, np.float32)
                 cen = np.repeat(np.stack([wp.to_pose_matrix()[:3, 3] for wp in waypoints]), fr["counts"], axis=0)
                 v = fr["point3"] - cen
                 v = v / np.linalg.norm(v, axis=1, keepdims=True)

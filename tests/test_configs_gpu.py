@@ -442,7 +442,11 @@ def test_simulator_export_reads_the_annotation_files(tmp_path, engine):
     assert len(np.unique(out["red"])) > 50                                  # not the default grey
 
 
-# ---- the packet kernel: same bytes as the per-ray kernel ----------------------------------------------------------
+# ---- the grid entry points / the packet kernel: same bytes as the per-ray kernel ------------------------------------
+# In the product library lrc_scan_grid_* run the per-ray kernel; the packet kernel lives in the laboratory build.  The two
+# tests below run in-process against the product library (the entry points, their argument checks, the routing) and once
+# more in a child process against liblidarcast_lab.so (test_packet_kernel_in_the_laboratory_build), where they compare
+# the packet kernel itself with the per-ray kernel.
 def _rot(yaw, pitch, roll):
     cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
     Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
@@ -519,6 +523,19 @@ def test_packet_kernel_is_bit_identical(engine):
             checked += int(hit.sum())
         scene.close()
     assert checked > 500000
+
+
+def test_packet_kernel_in_the_laboratory_build():
+    """The two packet-kernel tests again, in a child process that loads the laboratory build (LRC_LIB)."""
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    from conftest import REPO
+    env = dict(os.environ, LRC_LIB=entry.LAB_LIB, LRC_SECTOR="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_configs_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_packet_kernel_is_bit_identical or test_packet_kernel_full_size_c3"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_packet_kernel_full_size_c3(engine):

@@ -606,6 +606,74 @@ def test_cloud_rebuilt_from_triangle_ids(ctx):
     scene.reset_options()
 
 
+def test_cloud_assembly_with_own_records_and_device_range_stats(ctx):
+    """N-rank assembly where a rank's OWN rows are not rebuilt from ids but scattered from the records its trace wrote
+    (lrc_cloud_from_prims_own_dev): three slabs of two poses, every slab in turn playing "own" -- the assembled cloud
+    equals the single-process compaction bit for bit each time.  Then the ScanQuality range statistics of the assembled
+    rows on the device (lrc_cloud_range_stats_dev) against np.mean / np.std of np.linalg.norm(points) per pose."""
+    import torch
+    import lidarcast
+    from lidarcast import synth
+    from lidarcast._capi import LrcCompactIO
+    from lidar import IndoorLidar
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=4, seed=5, cell=0.04)
+    scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    k = sensor_small(lines=4, width=256, max_range=2.0)
+    poses = np.stack([pose(1.0 + 0.4 * i, 1.5, 1.0, yaw=0.37 * i) for i in range(6)])
+    dirs = IndoorLidar(k, np.eye(4)).sensor_directions()
+    P, N = len(poses), len(dirs)
+    want = ("t", "prim", "point3", "sem", "ins", "tile_count")
+    hits = lidarcast.DeviceHits(P * N, dev, want=want)
+    d_poses, d_dirs = torch.from_numpy(poses.reshape(P, 16)).to(dev), torch.from_numpy(dirs).to(dev)
+    rows = torch.zeros((P * N, 4), dtype=torch.float32, device=dev)
+    counts = torch.zeros(P, dtype=torch.int64, device=dev)
+    io = LrcCompactIO()
+    io.t, io.point3, io.sem, io.ins = (hits[a].data_ptr() for a in ("t", "point3", "sem", "ins"))
+    io.tile_count, io.counts, io.out_xyzl = hits["tile_count"].data_ptr(), counts.data_ptr(), rows.data_ptr()
+    scene.scan_poses_dev(d_poses, d_dirs, hits, k.max_range, st)
+    ctx.compact_dev(P, N, io, st)
+    torch.cuda.synchronize()
+    K = int(counts.sum().item())
+    assert 0 < K < P * N
+    pps, nslab, tps = 2, 3, N // 64
+    words = (pps * N + pps * tps + 3) // 4 * 4 + 8
+    slabs = torch.full((nslab * words,), -1, dtype=torch.int32, device=dev)
+    for r in range(nslab):
+        slabs[r * words:r * words + pps * N] = hits["prim"][r * pps * N:(r + 1) * pps * N]
+        slabs[r * words + pps * N:r * words + pps * N + pps * tps] = hits["tile_count"][r * pps * tps:(r + 1) * pps * tps]
+    for own in range(nslab):
+        # the own rank's records: a separate scan of just its poses (what a rank holds), local indexing
+        mine = lidarcast.DeviceHits(pps * N, dev, want=want)
+        scene.scan_poses_dev(d_poses[own * pps:(own + 1) * pps], d_dirs, mine, k.max_range, st)
+        oio = LrcCompactIO()
+        oio.t, oio.point3, oio.sem, oio.ins = (mine[a].data_ptr() for a in ("t", "point3", "sem", "ins"))
+        # poison the own slab's ids: they must not be read
+        poisoned = slabs.clone()
+        poisoned[own * words:own * words + pps * N] = 123456789
+        rows2 = torch.full_like(rows, 7.0)
+        counts2 = torch.zeros(P, dtype=torch.int64, device=dev)
+        scene.cloud_from_prims_dev(d_poses, d_dirs, poisoned, rows2, counts2, tile_count_t=poisoned[pps * N:],
+                                   poses_per_slab=pps, slab_stride_bytes=words * 4, stream=st, own_slab=own, own_io=oio)
+        torch.cuda.synchronize()
+        assert torch.equal(counts2, counts), own
+        assert torch.equal(rows2[:K].view(torch.int32), rows[:K].view(torch.int32)), own
+        assert bool((rows2[K:] == 7.0).all())
+    rng = torch.empty(P * N, dtype=torch.float32, device=dev)
+    mean = torch.empty(P, dtype=torch.float32, device=dev)
+    std = torch.empty(P, dtype=torch.float32, device=dev)
+    ctx.cloud_range_stats_dev(rows, counts, rng, mean, std, stream=st)
+    torch.cuda.synchronize()
+    pts = rows[:K, :3].cpu().numpy()
+    ends = np.cumsum(counts.cpu().numpy())
+    for p in range(P):
+        seg = pts[ends[p] - int(counts[p]):ends[p]]
+        r = np.linalg.norm(seg, axis=1)
+        assert r.dtype == np.float32
+        assert np.mean(r) == mean[p].item() and np.std(r) == std[p].item(), p
+
+
 def test_examples_run(tmp_path):
     """examples/ are part of the documentation: they must run as written."""
     import subprocess
@@ -959,9 +1027,10 @@ def test_kernel_variants_are_bit_identical():
     """Traversal order / fetch strategy / leaf size / builder must not change a single output byte.
     The product library with the scene built on the device (default) and on the host, with smaller leaves, with every
     split forced through the median fallback, on float32 nodes and on forced quantised images; then the laboratory build
-    (-DLRC_VARIANTS, liblidarcast_lab.so through LRC_LIB): scalar fetch off, leaf pairs, speculative postponement, private
-    refill, four-wide nodes, and the quantised path with every third / every ray sent through its redo route (the
-    route a ray takes when its closest candidate fails the box clause, which no input so far has made happen)."""
+    (-DLRC_VARIANTS, liblidarcast_lab.so through LRC_LIB): the packet kernel behind the grid entry point (on by default
+    there) and with it off, scalar fetch off, one triangle per leaf round trip, speculative postponement, private refill,
+    four-wide nodes, and every third / every ray sent through the redo route (the route a ray takes when its closest
+    candidate fails the box clause, which no input so far has made happen), on quantised and on float32 nodes."""
     import subprocess
     import sys
     import __graft_entry__ as entry
@@ -974,13 +1043,16 @@ def test_kernel_variants_are_bit_identical():
                 "leaves_of_1_host_builder": {"LRC_MAX_LEAF": "1", "LRC_DEVICE_BUILD": "0"},
                 "median_splits_only": {"LRC_BUILD_MEDIAN_ONLY": "1"}, "no_depth_slack": {"LRC_DEPTH_SLACK": "0"},
                 "float32_nodes": {"LRC_QNODES": "0"}, "quantised_nodes_forced": {"LRC_QNODES": "2"},
-                "lab_default": lab, "no_scalar_fetch": dict(lab, LRC_UNIFORM="0"), "leaf_pairs": dict(lab, LRC_LEAFW="2"),
-                "speculative": dict(lab, LRC_SPEC="1"), "refill_2": dict(lab, LRC_REFILL="2"),
+                "lab_default": lab, "lab_no_packet_kernel": dict(lab, LRC_SECTOR="0"),
+                "no_scalar_fetch": dict(lab, LRC_UNIFORM="0"), "leaf_singles": dict(lab, LRC_LEAFW="1"),
+                "speculative": dict(lab, LRC_SPEC="1"), "speculative_leaf_singles": dict(lab, LRC_SPEC="1", LRC_LEAFW="1"),
+                "refill_2": dict(lab, LRC_REFILL="2"),
                 "refill_4": dict(lab, LRC_REFILL="4"), "refill_2_w7": dict(lab, LRC_REFILL="2", LRC_REFILL_W="7"),
-                "quantised_leaf_pairs": dict(lab, LRC_QNODES="2", LRC_LEAFW="2"),
+                "quantised_leaf_singles": dict(lab, LRC_QNODES="2", LRC_LEAFW="1"),
                 "four_wide_nodes": dict(lab, LRC_QNODES="2", LRC_WIDE="1"),
                 "every_third_ray_redone": dict(lab, LRC_QNODES="2", LRC_DEBUG_FORCE_REDO="3"),
-                "every_ray_redone": dict(lab, LRC_QNODES="2", LRC_DEBUG_FORCE_REDO="1")}
+                "every_ray_redone": dict(lab, LRC_QNODES="2", LRC_DEBUG_FORCE_REDO="1"),
+                "every_ray_redone_float32_nodes": dict(lab, LRC_QNODES="0", LRC_DEBUG_FORCE_REDO="1")}
     digests = {}
     for name, env in variants.items():
         e = dict(os.environ)

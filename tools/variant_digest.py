@@ -20,7 +20,14 @@ k = Indoor8LineLidarIntrinsics(vertical_res=8, horizontal_res=1024, max_range=20
                                vertical_degrees=[25.0, 15.0, 5.0, 0.0, -5.0, -15.0, -25.0, -35.0])
 poses = np.stack([np.eye(4) for _ in range(4)])
 poses[:, :3, 3] = [(0.8, 1.2, 1.0), (1.6, 1.4, 1.0), (2.4, 1.6, 1.1), (3.2, 1.5, 0.9)]
-out = scene.scan_poses(poses, IndoorLidar(k, np.eye(4)).sensor_directions(), k.max_range)
+dirs = IndoorLidar(k, np.eye(4)).sensor_directions()
+out = scene.scan_poses(poses, dirs, k.max_range)
+# the same scan through the grid entry point (lrc_scan_grid_compact): the per-ray kernel in the product library, the packet
+# kernel in the laboratory build (LRC_SECTOR, default on there)
+from raycast_engine.raycast_engine_hip import RaycastEngineHIP  # noqa: E402
+grid = RaycastEngineHIP._derive_grid(dirs, k.horizontal_res)
+assert grid is not None
+frames = scene.scan_poses_compact(poses, dirs, k.max_range, want=("point3", "sem", "ins", "incident_deg"), grid=grid)
 rng = np.random.default_rng(1)
 soup = rng.uniform(-3, 3, (3000, 1, 3)) + rng.normal(scale=0.4, size=(3000, 3, 3))
 scene2 = lidarcast.Scene(ctx, soup.reshape(-1, 3), np.arange(9000).reshape(-1, 3))
@@ -31,4 +38,7 @@ h = hashlib.sha256()
 for res in (out, out2):
     for key in ("t", "prim", "normal3", "point3", "sem", "ins", "incident_deg"):
         h.update(res[key].tobytes())
+for key in ("point3", "sem", "ins", "incident_deg", "counts"):
+    h.update(np.ascontiguousarray(frames[key]).tobytes())
+assert frames["total"] == int(np.isfinite(out["t"]).sum())
 print(h.hexdigest(), int(np.isfinite(out["t"]).sum()), int(np.isfinite(out2["t"]).sum()))

@@ -6,7 +6,9 @@
 // The algorithm is bvh_build.cpp's, restated level by level:
 //   * a level = all inner nodes of one depth, in left-to-right order; every node owns a contiguous range of the
 //     primitive array (32-byte records: box + triangle row), which its split partitions into the other buffer;
-//   * nodes of <= 64 primitives are split by ONE WAVE each (k_small: primitive per lane, the 64 bins of an axis in
+//   * nodes of <= 16 primitives -- most nodes of the last levels -- four to a wave (k_tiny: a candidate split per
+//     primitive instead of per bin: the split "after bin b" changes only at occupied bins, so the occupied bins are the
+//     candidates; same costs, same first minimum), nodes of <= 64 primitives by ONE WAVE each (k_small: primitive per lane, the 64 bins of an axis in
 //     LDS, then bin per lane: prefix / suffix of boxes and counts by wave shuffles, costs in double precision,
 //     arg-min by butterfly), nodes of <= 1024 by one workgroup (k_medium: three waves evaluate the three axes side by
 //     side), larger ones by workgroups per 1024-primitive chunk with the bins of a node combined by integer atomics
@@ -35,6 +37,7 @@
 namespace lrc {
 namespace {
 
+constexpr int kTinyMax = 16;         // four nodes per wave (16 lanes each)
 constexpr int kSmallMax = 64;        // one wave per node
 constexpr int kMediumMax = 1024;     // one workgroup per node
 constexpr int kChunk = 1024;         // primitives per workgroup of the big-node kernels
@@ -75,7 +78,7 @@ struct BigWork {                     // one per big node of the current level
     uint32_t pad[4];
 };
 
-struct LevelCounters { uint32_t n_nodes, n_small, n_medium, n_big, n_leaves, max_leaf, n_median, error; };
+struct LevelCounters { uint32_t n_nodes, n_small, n_medium, n_big, n_leaves, max_leaf, n_median, error, n_tiny, pad[3]; };
 
 struct Params {
     const PrimRec* cur;
@@ -326,6 +329,153 @@ __global__ __launch_bounds__(256) void k_small(const Params P, const uint32_t* l
         if (cn <= (uint32_t)P.max_leaf) P.final_id[begin + pos] = pr.id;
     }
     if (lane == 0) {
+        nd.mid = begin + nL;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { nd.box[0][k] = lbox[k]; nd.box[1][k] = rbox[k]; }
+    }
+}
+
+// ---- nodes of <= 16 primitives: four to a wave ---------------------------------------------------------------------------
+// Lane i of a 16-lane group holds primitive i of its node and evaluates ONE candidate: the split after the bin its own
+// centroid falls into.  The host's sweep over the 64 bins changes the partition only at occupied bins, equal partitions have
+// equal costs and the first minimum wins, so the minimum over the occupied bins with ties to the lower bin is the host's
+// choice.  The group's primitives sit in LDS (8 words each: box as ordered ints, the three bin numbers, the row); every lane
+// walks the 16 records (broadcast reads) and grows the left or the right side of its candidate.
+DI int group_min(int v) {
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) v = imin(v, __shfl_xor(v, d, 64));
+    return v;
+}
+DI int group_max(int v) {
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) v = imax(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_tiny(const Params P, const uint32_t* list, uint32_t n_list) {
+    __shared__ uint4 s_rec[4][4 * kTinyMax * 2];       // per wave: 4 groups x 16 primitives x 2 x uint4
+    const uint32_t wave0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;       // first node of this wave
+    if (wave0 >= n_list) return;                    // whole waves leave; no workgroup barrier below
+    const int lane = threadIdx.x & 63, gl = lane & 15, g0 = lane & 48;
+    uint4* rec = s_rec[threadIdx.x >> 6] + (size_t)(g0 >> 4) * kTinyMax * 2;
+    const uint32_t w = wave0 + (uint32_t)(g0 >> 4);
+    const bool node_ok = w < n_list;
+    const uint32_t g = node_ok ? list[w] : 0u;
+    TNode& nd = P.nodes[g];
+    const uint32_t begin = node_ok ? nd.begin : 0u, n = node_ok ? nd.end - nd.begin : 0u;
+    const int depth = (int)nd.depth;
+    const bool act = (uint32_t)gl < n;
+    LoadedPrim pr{};
+    if (act) pr = load_prim(P.cur + begin + gl);
+    int cb[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        cb[k] = group_min(act ? enc(pr.c[k]) : kEncPosMax);
+        cb[3 + k] = group_max(act ? enc(pr.c[k]) : kEncNegMax);
+    }
+    int mybin[3] = {0, 0, 0};
+    bool ok3[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const float lo = dec(cb[ax]), ext = dec(cb[3 + ax]) - lo;
+        ok3[ax] = (ext > 0.0f) && !P.median_only;
+        mybin[ax] = ok3[ax] ? bin_of(pr.c[ax], lo, (float)kBinsN / ext) : 0;
+    }
+    rec[gl * 2] = make_uint4((uint32_t)enc(pr.lo[0]), (uint32_t)enc(pr.lo[1]), (uint32_t)enc(pr.lo[2]), (uint32_t)enc(pr.hi[0]));
+    rec[gl * 2 + 1] = make_uint4((uint32_t)enc(pr.hi[1]), (uint32_t)enc(pr.hi[2]),
+                                 (uint32_t)mybin[0] | ((uint32_t)mybin[1] << 8) | ((uint32_t)mybin[2] << 16) | (act ? 1u << 24 : 0u), pr.id);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    double best_cost = 1.7976931348623157e308;
+    int best_axis = -1, best_bin = -1;
+    int lbox[6], rbox[6];
+    uint32_t nL = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { lbox[k] = 0; rbox[k] = 0; }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        if (!__builtin_amdgcn_ballot_w64(ok3[ax])) continue;         // no group of this wave has an extent on this axis
+        int L[6] = {kEncPosMax, kEncPosMax, kEncPosMax, kEncNegMax, kEncNegMax, kEncNegMax};
+        int R[6] = {kEncPosMax, kEncPosMax, kEncPosMax, kEncNegMax, kEncNegMax, kEncNegMax};
+        uint32_t lc = 0, rc = 0;
+        const int bi = mybin[ax];
+#pragma unroll 4
+        for (int j = 0; j < kTinyMax; ++j) {
+            const uint4 a = rec[j * 2], b = rec[j * 2 + 1];
+            const bool valid = (b.z >> 24) != 0u;
+            const int bj = (int)((b.z >> (8 * ax)) & 0xFFu);
+            const bool left = valid && bj <= bi, right = valid && bj > bi;
+            const int v[6] = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int cl = k < 3 ? imin(L[k], v[k]) : imax(L[k], v[k]), cr = k < 3 ? imin(R[k], v[k]) : imax(R[k], v[k]);
+                L[k] = left ? cl : L[k];
+                R[k] = right ? cr : R[k];
+            }
+            lc += left ? 1u : 0u;
+            rc += right ? 1u : 0u;
+        }
+        double c = __builtin_inf();
+        if (act && ok3[ax] && lc > 0u && rc > 0u) c = half_area(L) * (double)lc + half_area(R) * (double)rc;
+        int bb = bi, src = lane;
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) {
+            const double oc = __shfl_xor(c, d, 64);
+            const int ob = __shfl_xor(bb, d, 64), os = __shfl_xor(src, d, 64);
+            if (oc < c || (oc == c && ob < bb)) { c = oc; bb = ob; src = os; }
+        }
+        // the winner's two sides (every lane of the group reads them from the winning lane)
+        int wl[6], wr[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { wl[k] = __shfl(L[k], src, 64); wr[k] = __shfl(R[k], src, 64); }
+        const uint32_t wlc = __shfl(lc, src, 64);
+        if (c < best_cost) {
+            best_cost = c; best_axis = ax; best_bin = bb; nL = wlc;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { lbox[k] = wl[k]; rbox[k] = wr[k]; }
+        }
+    }
+    bool pred = false, have_split = false;
+    if (best_axis >= 0) {
+        have_split = fits(nL, depth + 1, P) && fits(n - nL, depth + 1, P);
+        const int mb = best_axis == 0 ? mybin[0] : (best_axis == 1 ? mybin[1] : mybin[2]);
+        pred = mb <= best_bin;
+    }
+    const bool need_median = node_ok && !have_split;
+    if (__builtin_amdgcn_ballot_w64(need_median)) {       // some group of the wave takes the median fallback
+        const int ax = median_axis(cb);
+        const float myc = ax == 0 ? pr.c[0] : (ax == 1 ? pr.c[1] : pr.c[2]);
+        uint32_t rank = 0;
+        for (int j = 0; j < kTinyMax; ++j) {
+            const float cj = __shfl(myc, g0 + j, 64);
+            const uint32_t ij = __shfl(pr.id, g0 + j, 64);
+            rank += ((uint32_t)j < n && key_less(cj, ij, myc, pr.id)) ? 1u : 0u;
+        }
+        const uint32_t half = (n + 1u) / 2u;
+        const bool mp = rank < half;
+        int ml[6], mr[6];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ml[k] = group_min(act && mp ? enc(pr.lo[k]) : kEncPosMax);
+            ml[3 + k] = group_max(act && mp ? enc(pr.hi[k]) : kEncNegMax);
+            mr[k] = group_min(act && !mp ? enc(pr.lo[k]) : kEncPosMax);
+            mr[3 + k] = group_max(act && !mp ? enc(pr.hi[k]) : kEncNegMax);
+        }
+        if (need_median) {
+            nL = half; pred = mp;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { lbox[k] = ml[k]; rbox[k] = mr[k]; }
+        }
+    }
+    const unsigned long long am = __ballot(act), lm = __ballot(act && pred);
+    const uint32_t gam = (uint32_t)(am >> g0) & 0xFFFFu, glm = (uint32_t)(lm >> g0) & 0xFFFFu;
+    const uint32_t below = (1u << gl) - 1u;
+    if (act) {
+        const uint32_t pos = pred ? (uint32_t)__popc(glm & below) : nL + (uint32_t)__popc(gam & ~glm & below);
+        store_prim(P.nxt + begin + pos, pr);
+        const uint32_t cn = pred ? nL : n - nL;
+        if (cn <= (uint32_t)P.max_leaf) P.final_id[begin + pos] = pr.id;
+    }
+    if (gl == 0 && node_ok) {
         nd.mid = begin + nL;
 #pragma unroll
         for (int k = 0; k < 6; ++k) { nd.box[0][k] = lbox[k]; nd.box[1][k] = rbox[k]; }
@@ -782,8 +932,8 @@ __global__ __launch_bounds__(256) void k_emit_count(const TNode* nodes, uint32_t
 
 __global__ __launch_bounds__(256) void k_emit_write(TNode* nodes, uint32_t base, uint32_t n, uint32_t next_base,
                                                     int max_leaf, const uint32_t* partial, const BigWork* work,
-                                                    uint32_t* list_small, uint32_t* list_medium, uint32_t* list_big,
-                                                    LevelCounters* next) {
+                                                    uint32_t* list_tiny, uint32_t* list_small, uint32_t* list_medium,
+                                                    uint32_t* list_big, LevelCounters* next) {
     __shared__ uint32_t s_red[256];
     __shared__ uint32_t s_wave[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -834,7 +984,8 @@ __global__ __launch_bounds__(256) void k_emit_write(TNode* nodes, uint32_t base,
                 ch.cb_valid = 1;
                 for (int k = 0; k < 6; ++k) ch.cb[k] = work[nd->work].ccb[c][k];
             }
-            if (m <= (uint32_t)kSmallMax) list_small[atomicAdd(&next->n_small, 1u)] = g;
+            if (m <= (uint32_t)kTinyMax) list_tiny[atomicAdd(&next->n_tiny, 1u)] = g;
+            else if (m <= (uint32_t)kSmallMax) list_small[atomicAdd(&next->n_small, 1u)] = g;
             else if (m <= (uint32_t)kMediumMax) list_medium[atomicAdd(&next->n_medium, 1u)] = g;
             else list_big[atomicAdd(&next->n_big, 1u)] = g;
         } else {
@@ -1042,7 +1193,7 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
         Carver c{nullptr};
         if (!on_device) { c.take<float>(3 * V); c.take<uint32_t>(3 * (size_t)T); c.take<uint16_t>(T); c.take<uint16_t>(T); }
         c.take<PrimRec>(T); c.take<PrimRec>(T); c.take<TNode>(T); c.take<uint32_t>(T);
-        for (int k = 0; k < 6; ++k) c.take<uint32_t>(list_cap);
+        for (int k = 0; k < 8; ++k) c.take<uint32_t>(list_cap);
         c.take<BigWork>(nbig_cap); c.take<uint32_t>(nbig_cap + 1); c.take<int>(nbig_cap * 3 * 7 * kBinsN);
         c.take<uint32_t>(nbig_cap);
         c.take<uint32_t>(list_cap / 256 + 2);
@@ -1077,8 +1228,8 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     PrimRec* bufB = c.take<PrimRec>(T);
     TNode* nodes = c.take<TNode>(T);
     uint32_t* final_id = c.take<uint32_t>(T);
-    uint32_t* lists[2][3];
-    for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) lists[a][k] = c.take<uint32_t>(list_cap);
+    uint32_t* lists[2][4];                  // per level parity: small, medium, big, tiny
+    for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) lists[a][k] = c.take<uint32_t>(list_cap);
     BigWork* work = c.take<BigWork>(nbig_cap);
     uint32_t* chunk_start = c.take<uint32_t>(nbig_cap + 1);
     int* gbins = c.take<int>(nbig_cap * 3 * 7 * kBinsN);
@@ -1115,11 +1266,12 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
         uint32_t first = 0;
         LevelCounters l0{};
         l0.n_nodes = 1;
-        if (T <= (uint32_t)kSmallMax) l0.n_small = 1; else if (T <= (uint32_t)kMediumMax) l0.n_medium = 1; else l0.n_big = 1;
+        if (T <= (uint32_t)kTinyMax) l0.n_tiny = 1; else if (T <= (uint32_t)kSmallMax) l0.n_small = 1;
+        else if (T <= (uint32_t)kMediumMax) l0.n_medium = 1; else l0.n_big = 1;
         DB_HIP(hipMemcpyAsync(nodes, &root, sizeof(root), hipMemcpyHostToDevice, st));
         DB_HIP(hipMemcpyAsync(bounds, b8, sizeof(b8), hipMemcpyHostToDevice, st));
         DB_HIP(hipMemcpyAsync(counters, &l0, sizeof(l0), hipMemcpyHostToDevice, st));
-        for (int k = 0; k < 3; ++k) DB_HIP(hipMemcpyAsync(lists[0][k], &first, 4, hipMemcpyHostToDevice, st));
+        for (int k = 0; k < 4; ++k) DB_HIP(hipMemcpyAsync(lists[0][k], &first, 4, hipMemcpyHostToDevice, st));
         DB_HIP(hipStreamSynchronize(st));      // the stack temporaries above must outlive their copies
     }
     hipLaunchKernelGGL(k_check_verts, dim3((uint32_t)((3 * V + 255) / 256)), dim3(256), 0, st, d_verts, 3 * V, counters);
@@ -1196,17 +1348,19 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
         if (lc.n_medium) hipLaunchKernelGGL(k_medium, dim3(lc.n_medium), dim3(256), 0, st, P, (const uint32_t*)L[1]);
         if (lc.n_small)
             hipLaunchKernelGGL(k_small, dim3((lc.n_small + 3) / 4), dim3(256), 0, st, P, (const uint32_t*)L[0], lc.n_small);
+        if (lc.n_tiny)
+            hipLaunchKernelGGL(k_tiny, dim3((lc.n_tiny + 15) / 16), dim3(256), 0, st, P, (const uint32_t*)L[3], lc.n_tiny);
         const uint32_t nblk = (lc.n_nodes + 255) / 256;
         hipLaunchKernelGGL(k_emit_count, dim3(nblk), dim3(256), 0, st, (const TNode*)nodes, base, lc.n_nodes, max_leaf, partial);
         hipLaunchKernelGGL(k_emit_write, dim3(nblk), dim3(256), 0, st, nodes, base, lc.n_nodes, base + lc.n_nodes, max_leaf,
-                           (const uint32_t*)partial, (const BigWork*)work, Ln[0], Ln[1], Ln[2], counters + level + 1);
+                           (const uint32_t*)partial, (const BigWork*)work, Ln[3], Ln[0], Ln[1], Ln[2], counters + level + 1);
         DB_HIP(hipMemcpyAsync(&land->lc, counters + level + 1, sizeof(LevelCounters), hipMemcpyDeviceToHost, st));
         DB_HIP(hipStreamSynchronize(st));
         base += lc.n_nodes;
         lc = land->lc;
         num_leaves += lc.n_leaves;
         max_leaf_seen = std::max(max_leaf_seen, lc.max_leaf);
-        if (lc.n_small + lc.n_medium + lc.n_big != lc.n_nodes) {
+        if (lc.n_tiny + lc.n_small + lc.n_medium + lc.n_big != lc.n_nodes) {
             if (err) *err = "device BVH build: work lists do not add up";
             return LRC_ERR_INTERNAL;
         }

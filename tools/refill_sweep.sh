@@ -3,6 +3,8 @@
 # private-refill variants (K rays per lane; W = waves per SIMD the register allocator leaves room for).  GPU box only.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
+P=$(cd "$(dirname "$0")/.." && pwd)/indoor-point-cloud-datasets-controllable-generation-method-for-mobile-robots-3d-scene-perception_amd
+export LRC_LIB=$P/liblidarcast_lab.so   # the refill kernels live in the laboratory build
 for cfg in "" "LRC_REFILL=2" "LRC_REFILL=2 LRC_REFILL_W=7" "LRC_REFILL=4" "LRC_REFILL=4 LRC_REFILL_W=7"; do
   echo "== ${cfg:-default}"
   env $cfg timeout -k 10 120 python3 tools/trace_time.py "$@" 2>&1 | tail -1

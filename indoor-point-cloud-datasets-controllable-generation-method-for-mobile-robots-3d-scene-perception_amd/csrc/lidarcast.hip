@@ -971,13 +971,30 @@ __global__ __launch_bounds__(1024) void compact_base_kernel(const uint32_t* supe
 }
 
 // Pass B: scatter the kept entries; the first workgroups also write the per-segment counts.
+// exclusive prefix of the super-tile totals at super tile s, formed on the spot: a wave sums at most a few hundred
+// numbers, which is cheaper than the launch of a kernel that would tabulate them (compact_base_kernel)
+__device__ __forceinline__ uint64_t super_prefix_wave(const uint32_t* __restrict__ total, uint64_t s, uint32_t lane) {
+    uint64_t acc = 0;
+    for (uint64_t j = lane; j < s; j += 64) acc += total[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    return acc;
+}
+__device__ __forceinline__ uint64_t super_prefix_thread(const uint32_t* __restrict__ total, uint64_t s) {
+    uint64_t acc = 0;
+    for (uint64_t j = 0; j < s; ++j) acc += total[j];
+    return acc;
+}
+
 // tile_base: index of this call's tile 0 in tile_off / super_base (non-zero when the offsets come from a scan over the
 // tiles of several ranks and this call scatters one rank's records into the assembled cloud).
+// super_total != NULL: the bases of the super tiles are summed here from the totals (super_base is not read).
 __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const lrc_compact_io io,
                                                                  uint64_t seg_len, uint64_t tps,
                                                                  uint64_t ntiles, uint64_t nseg,
                                                                  const uint32_t* tile_off,
-                                                                 const uint64_t* super_base, uint64_t tile_base) {
+                                                                 const uint64_t* super_base, uint64_t tile_base,
+                                                                 const uint32_t* super_total) {
     const uint32_t lane = threadIdx.x & 63u;
     if (io.counts) {
         // one thread per segment: count = global offset of its end tile - global offset of its first tile
@@ -985,9 +1002,12 @@ __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const lrc_compa
         if (sg < nseg) {
             const uint64_t nsuper = (ntiles + 1023) / 1024;
             const uint64_t g0 = sg * tps, g1 = g0 + tps;
-            const uint64_t o0 = g0 >= ntiles ? super_base[nsuper] : super_base[g0 >> 10] + tile_off[g0];
-            const uint64_t o1 = g1 >= ntiles ? super_base[nsuper] : super_base[g1 >> 10] + tile_off[g1];
-            io.counts[sg] = o1 - o0;
+            auto at = [&](uint64_t g) -> uint64_t {
+                if (super_total) return g >= ntiles ? super_prefix_thread(super_total, nsuper)
+                                                    : super_prefix_thread(super_total, g >> 10) + tile_off[g];
+                return g >= ntiles ? super_base[nsuper] : super_base[g >> 10] + tile_off[g];
+            };
+            io.counts[sg] = at(g1) - at(g0);
         }
     }
     const uint64_t tile = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -998,9 +1018,11 @@ __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const lrc_compa
     bool keep = false;
     if (i < seg_len) keep = io.t[src] < __builtin_inff();
     const unsigned long long m = __ballot(keep);
-    if (!keep) return;
+    if (m == 0ull) return;
     const uint64_t gt = tile_base + tile;
-    const uint64_t tbase = super_base[gt >> 10] + tile_off[gt];
+    const uint64_t sbase = super_total ? super_prefix_wave(super_total, gt >> 10, lane) : super_base[gt >> 10];
+    if (!keep) return;
+    const uint64_t tbase = sbase + tile_off[gt];
     const uint64_t dst = tbase + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
     if (io.out_xyzl) {
         const float* sp = io.point3 + src * 3;
@@ -1975,13 +1997,17 @@ int lrc_compact_dev(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_com
     const uint64_t nsuper = (ntiles + 1023) / 1024;
     hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(1024), 0, st, cnt, ntiles, (uint64_t)0,
                        sc.d_tile_off, ntiles, sc.d_super_total);
-    hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)sc.d_super_total,
-                       sc.d_super_base, nsuper);
+    // few super tiles (a C3 scan has 64): every scatter wave sums the totals in front of it itself, one launch less
+    const bool inline_bases = nsuper <= 512;
+    if (!inline_bases)
+        hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)sc.d_super_total,
+                           sc.d_super_base, nsuper);
     // the scatter grid must also cover the threads that write the per-segment counts (one per segment)
     const uint64_t need = io->counts ? (nseg + kBlock - 1) / kBlock : 0;
     const uint64_t grid = nblocks > need ? nblocks : need;
     hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, st, *io, seg_len, tps,
-                       ntiles, nseg, (const uint32_t*)sc.d_tile_off, (const uint64_t*)sc.d_super_base, (uint64_t)0);
+                       ntiles, nseg, (const uint32_t*)sc.d_tile_off, (const uint64_t*)sc.d_super_base, (uint64_t)0,
+                       inline_bases ? (const uint32_t*)sc.d_super_total : (const uint32_t*)nullptr);
     LRC_HIP(hipGetLastError());
     return LRC_OK;
 }
@@ -2148,7 +2174,7 @@ int lrc_cloud_from_prims_own_dev(lrc_scene* s, const double* d_poses16, uint64_t
     io.out_xyzl = d_out_xyzl;
     const uint64_t nblocks = (own_tiles + kBlock / 64 - 1) / (kBlock / 64);
     hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, io, N, tps, own_tiles, own_poses,
-                       (const uint32_t*)q.tile_off, (const uint64_t*)q.super_base, first_pose * tps);
+                       (const uint32_t*)q.tile_off, (const uint64_t*)q.super_base, first_pose * tps, (const uint32_t*)nullptr);
     LRC_HIP(hipGetLastError());
     return LRC_OK;
 }

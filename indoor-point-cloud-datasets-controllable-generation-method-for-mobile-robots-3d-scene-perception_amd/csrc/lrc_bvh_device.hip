@@ -205,6 +205,8 @@ __global__ __launch_bounds__(256) void k_init_prims(const float* verts3, uint64_
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (threadIdx.x < 12) s_red[threadIdx.x] = (threadIdx.x % 6) < 3 ? kEncPosMax : kEncNegMax;
     __syncthreads();
+    int red[12] = {kEncPosMax, kEncPosMax, kEncPosMax, kEncNegMax, kEncNegMax, kEncNegMax,
+                   kEncPosMax, kEncPosMax, kEncPosMax, kEncNegMax, kEncNegMax, kEncNegMax};
     if (t < T) {
         const uint32_t i0 = tris3[3 * (size_t)t], i1 = tris3[3 * (size_t)t + 1], i2 = tris3[3 * (size_t)t + 2];
         if (i0 >= V || i1 >= V || i2 >= V) {
@@ -219,12 +221,18 @@ __global__ __launch_bounds__(256) void k_init_prims(const float* verts3, uint64_
                 const int lo = imin(imin(a, b), c), hi = imax(imax(a, b), c);
                 r.lo[k] = dec(lo); r.hi[k] = dec(hi);
                 r.c[k] = 0.5f * r.lo[k] + 0.5f * r.hi[k];
-                atomicMin(&s_red[k], lo); atomicMax(&s_red[3 + k], hi);
-                const int ce = enc(r.c[k]);
-                atomicMin(&s_red[6 + k], ce); atomicMax(&s_red[9 + k], ce);
+                red[k] = lo; red[3 + k] = hi;
+                red[6 + k] = red[9 + k] = enc(r.c[k]);
             }
             store_prim(prims + t, r);
         }
+    }
+    // scene bounds and the root's centroid bounds: wave butterfly, then one LDS atomic per wave and value
+#pragma unroll
+    for (int k = 0; k < 12; ++k) red[k] = (k % 6) < 3 ? wave_min(red[k]) : wave_max(red[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { if ((k % 6) < 3) atomicMin(&s_red[k], red[k]); else atomicMax(&s_red[k], red[k]); }
     }
     __syncthreads();
     if (threadIdx.x < 6) {

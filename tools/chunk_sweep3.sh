@@ -1,0 +1,15 @@
+#!/bin/bash
+# tools/chunk_sweep3.sh -- the pose-striped XCD order (default rule: 16 chunks per pose) against eight contiguous tile
+# ranges (LRC_TILE_CHUNK=-1), alternating, over sensor shapes and scenes.  GPU box only.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd $R
+export LRC_TT_WANT=t,prim,normal3,point3,sem,ins,tile_count
+for sc in ${SCENES:-synth_A6_office2 synth_rough_A6 synth_A1_office synth_hall}; do
+  for shape in "32 2048 64" "16 1024 128" "64 4096 16" "32 4096 32" "16 2048 64" "128 1024 32" "32 2048 8"; do
+    set -- $shape
+    for rep in 1 2; do
+      echo -n "contiguous " ; LRC_TILE_CHUNK=-1 timeout -k 10 120 python3 tools/trace_time.py $sc $1 $2 $3 2>&1 | tail -1
+      echo -n "striped " ; timeout -k 10 120 python3 tools/trace_time.py $sc $1 $2 $3 2>&1 | tail -1
+    done
+  done
+done

@@ -171,7 +171,6 @@ struct TraceParams {
     const float4* nodes_n4;    // ... and 128 B per node as normalised float32
     uint32_t stack_cap;        // entries of the per-lane LDS stack
     uint32_t tile_chunk_log2;  // 0: eight contiguous tile ranges, one per XCD; k + 1: chunks of 2^k tiles round robin
-    uint32_t dist_bits;        // LRC_DEADPOP (A/B): bits of a stack entry that carry the pushed child's entry distance (0: none)
     uint32_t force_redo;       // test hook (LRC_DEBUG_FORCE_REDO=m): rays with gid % m == 0 take the redo path as well
     float qbase[3], qW[3], qinvW[3];   // normalised coordinate n = (x - qbase) * qinvW in [2, 4); qW = 1 / qinvW = 2^k
     // inputs
@@ -482,50 +481,6 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
         int ref = 0;   // root
         // descend into the nearer hit child, push the other; nothing hit -> pop, or (stack empty) continue with the
         // empty leaf so that the outer loop ends
-#ifdef LRC_DEADPOP
-        // A/B experiment: a stack entry carries, in its top B bits, a lower bound of the pushed child's entry distance (16
-        // octaves from 2^-9, B - 4 mantissa bits, truncated); a pop whose bound already lies behind the closest hit is
-        // skipped without fetching the node (its children's intervals nest inside its own: all of them would fail).
-        const uint32_t B = p.dist_bits, RB = 32u - B, M = B - 4u;
-        auto pack = [&](int r, float nfar) -> int {
-            if (!B) return r;
-            int c = (__float_as_int(nfar) >> (23u - M)) - (int)(118u << M);
-            c = c < 0 ? 0 : (c > (int)((1u << B) - 1u) ? (int)((1u << B) - 1u) : c);
-            return (int)(((uint32_t)c << RB) | ((uint32_t)r & ((1u << RB) - 1u)));
-        };
-        // pops until an entry that may still matter; false: the stack is empty
-        auto pop = [&]() -> bool {
-            while (sp > 0) {
-                --sp;
-                const int e = s_stack[sp * kTBlock + tid];
-                if (!B) { ref = e; return true; }
-                const uint32_t code = (uint32_t)e >> RB;
-                const float tlo = __uint_as_float((code + (118u << M)) << (23u - M));
-                if (code != 0u && tlo > tbest) continue;
-                ref = (int)((uint32_t)e << B) >> B;
-                return true;
-            }
-            return false;
-        };
-        auto choose = [&](float n0, float f0, float n1, float f1, int r0, int r1) {
-            if (STATS) st_nodes += 1u;
-            const bool h0 = (n0 <= f0) & (n0 <= tbest);
-            const bool h1 = (n1 <= f1) & (n1 <= tbest);
-            if (h0 & h1) {
-                const bool first0 = n0 <= n1;
-                s_stack[sp * kTBlock + tid] = pack(first0 ? r1 : r0, first0 ? n1 : n0);
-                ++sp;
-                ref = first0 ? r0 : r1;
-            } else if (h0) {
-                ref = r0;
-            } else if (h1) {
-                ref = r1;
-            } else {
-                if (STATS) st_dead += 1u;
-                if (!pop()) ref = ~0;   // empty leaf
-            }
-        };
-#else
         auto choose = [&](float n0, float f0, float n1, float f1, int r0, int r1) {
             if (STATS) st_nodes += 1u;
             const bool h0 = (n0 <= f0) & (n0 <= tbest);
@@ -548,7 +503,6 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
                 ref = s_stack[sp * kTBlock + tid];
             }
         };
-#endif
         // one inner-node step on a float32 node (world space, or the normalised image on the scalar path)
         auto step = [&](const F4 q0, const F4 q1, const F4 q2, const F4 q3) {
             float n0, f0, n1, f1;
@@ -731,13 +685,9 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
             }
             if (SPEC) leaf(pending);
             leaf(ref);
-#ifdef LRC_DEADPOP
-            if (!pop()) break;
-#else
             if (sp == 0) break;
             --sp;
             ref = s_stack[sp * kTBlock + tid];
-#endif
         }
         if (!INLINE_CLAUSE) {
             if (best_slot != 0xFFFFFFFFu) {       // the box clause of the closest candidate, in world coordinates
@@ -1754,19 +1704,6 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
     const uint32_t depth = s->info.max_depth < 1 ? 1 : s->info.max_depth;
     const size_t lds = (size_t)depth * kTBlock * sizeof(int);
     p.stack_cap = depth;
-    p.dist_bits = 0;
-#ifdef LRC_DEADPOP
-    {
-        uint64_t max_enc = s->info.num_slots * 8 + 7;
-        if (s->info.num_nodes > max_enc) max_enc = s->info.num_nodes;
-        int bits = 0;
-        while ((1ull << bits) <= max_enc) ++bits;          // magnitude bits; + 1 sign bit
-        int B = 31 - bits;
-        if (B > 8) B = 8;
-        p.dist_bits = B >= 5 ? (uint32_t)B : 0u;
-        if (env_int("LRC_DEADPOP_OFF", 0)) p.dist_bits = 0;
-    }
-#endif
     // Workgroup -> tile order.  A pose-batched scan deals every pose's tiles to the 8 XCDs in 16 chunks: each XCD works on
     // every pose (the poses of a trajectory cost differently: balance) but always on the same sixteenth-pairs of the scan
     // pattern, so what its L2 holds after one pose is what the next pose needs.  Other launches, and
@@ -1784,11 +1721,13 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
             if (chunk >= 16 && (chunk & (chunk - 1)) == 0) { uint32_t k = 0; while ((1ull << k) < chunk) ++k; p.tile_chunk_log2 = k + 1; }
         }
     }
-    {   // A/B knob: LRC_TILE_CHUNK = n (power of two) tiles per chunk, -1 = contiguous ranges
+#ifdef LRC_VARIANTS
+    {   // A/B knob (tools/chunk_sweep*.sh): LRC_TILE_CHUNK = n (power of two) tiles per chunk, -1 = contiguous ranges
         static const int tc = env_int("LRC_TILE_CHUNK", 0);
         if (tc < 0) p.tile_chunk_log2 = 0;
         if (tc > 0 && (tc & (tc - 1)) == 0) { uint32_t k = 0; while ((1 << k) < tc) ++k; p.tile_chunk_log2 = k + 1; }
     }
+#endif
 #ifdef LRC_VARIANTS
     {
         const int rc = launch_trace_lab(s, p, gen, st, stats, nblk, lds, depth);

@@ -1028,7 +1028,8 @@ def test_kernel_variants_are_bit_identical():
     The product library with the scene built on the device (default) and on the host, with smaller leaves, with every
     split forced through the median fallback, on float32 nodes and on forced quantised images; then the laboratory build
     (-DLRC_VARIANTS, liblidarcast_lab.so through LRC_LIB): the packet kernel behind the grid entry point (on by default
-    there) and with it off, scalar fetch off, one triangle per leaf round trip, speculative postponement, private refill,
+    there) and with it off, the workgroup -> tile order (XCD striping, the default for this scan, against contiguous ranges
+    and another chunk size), scalar fetch off, one triangle per leaf round trip, speculative postponement, private refill,
     four-wide nodes, and every third / every ray sent through the redo route (the route a ray takes when its closest
     candidate fails the box clause, which no input so far has made happen), on quantised and on float32 nodes."""
     import subprocess
@@ -1044,6 +1045,8 @@ def test_kernel_variants_are_bit_identical():
                 "median_splits_only": {"LRC_BUILD_MEDIAN_ONLY": "1"}, "no_depth_slack": {"LRC_DEPTH_SLACK": "0"},
                 "float32_nodes": {"LRC_QNODES": "0"}, "quantised_nodes_forced": {"LRC_QNODES": "2"},
                 "lab_default": lab, "lab_no_packet_kernel": dict(lab, LRC_SECTOR="0"),
+                "contiguous_tile_ranges": dict(lab, LRC_SECTOR="0", LRC_TILE_CHUNK="-1"),
+                "tile_chunks_of_32": dict(lab, LRC_SECTOR="0", LRC_TILE_CHUNK="32"),
                 "no_scalar_fetch": dict(lab, LRC_UNIFORM="0"), "leaf_singles": dict(lab, LRC_LEAFW="1"),
                 "speculative": dict(lab, LRC_SPEC="1"), "speculative_leaf_singles": dict(lab, LRC_SPEC="1", LRC_LEAFW="1"),
                 "refill_2": dict(lab, LRC_REFILL="2"),

@@ -9,7 +9,7 @@ for sc in ${SCENES:-synth_A6_office2 synth_rough_A6 synth_A1_office synth_hall};
     set -- $shape
     for rep in 1 2 3; do
       for c in ${CHUNKS:-0 64 128}; do
-        echo -n "chunk=$c " ; LRC_TILE_CHUNK=$c timeout -k 10 120 python3 tools/trace_time.py $sc $1 $2 $3 2>&1 | tail -1
+        echo -n "chunk=$c " ; LRC_LIB=$R/indoor-point-cloud-datasets-controllable-generation-method-for-mobile-robots-3d-scene-perception_amd/liblidarcast_lab.so LRC_TILE_CHUNK=$c timeout -k 10 120 python3 tools/trace_time.py $sc $1 $2 $3 2>&1 | tail -1
       done
     done
   done

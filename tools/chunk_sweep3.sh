@@ -8,7 +8,7 @@ for sc in ${SCENES:-synth_A6_office2 synth_rough_A6 synth_A1_office synth_hall};
   for shape in "32 2048 64" "16 1024 128" "64 4096 16" "32 4096 32" "16 2048 64" "128 1024 32" "32 2048 8"; do
     set -- $shape
     for rep in 1 2; do
-      echo -n "contiguous " ; LRC_TILE_CHUNK=-1 timeout -k 10 120 python3 tools/trace_time.py $sc $1 $2 $3 2>&1 | tail -1
+      echo -n "contiguous " ; LRC_LIB=$R/indoor-point-cloud-datasets-controllable-generation-method-for-mobile-robots-3d-scene-perception_amd/liblidarcast_lab.so LRC_TILE_CHUNK=-1 timeout -k 10 120 python3 tools/trace_time.py $sc $1 $2 $3 2>&1 | tail -1
       echo -n "striped " ; timeout -k 10 120 python3 tools/trace_time.py $sc $1 $2 $3 2>&1 | tail -1
     done
   done

@@ -8,6 +8,9 @@ mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 700 python3 -m pytest tests -m gpu -x -q -s > $O/gputests.log 2>&1; echo "gpu tests exit $?" > $O/log.txt
 tail -3 $O/gputests.log >> $O/log.txt
+# counters first: bench.py derives roofline.frac from the counter file of THIS binary (source fingerprint)
+tools/pmc.sh r3p/pmc > /dev/null 2>&1; cp gpurun_out/r3p/pmc/summary.txt $O/pmc_summary.txt; cp gpurun_out/r3p/pmc/pmc.json $O/pmc_synth_A6_office2.json
+cp $O/pmc_synth_A6_office2.json profiles/pmc_latest.json; cp $O/pmc_synth_A6_office2.json profiles/pmc_synth_A6_office2.json
 timeout -k 10 300 python3 bench.py --steps 50 --warmup 5 > $O/bench.json 2> $O/bench.err || { echo bench failed >> $O/log.txt; tail -5 $O/bench.err >> $O/log.txt; }
 echo "bench done" >> $O/log.txt
 cd /tmp
@@ -17,9 +20,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bui
 find $O/build_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/build_kernel_stats.csv
 echo "stats done" >> $O/log.txt
 cd $R
-tools/pmc.sh r3p/pmc > /dev/null 2>&1; cp gpurun_out/r3p/pmc/summary.txt $O/pmc_summary.txt; cp gpurun_out/r3p/pmc/pmc.json $O/pmc_synth_A6_office2.json
 for sc in synth_rough_A6 synth_hall; do
   PMC_SCENE=$sc tools/pmc.sh r3p/pmc_$sc > /dev/null 2>&1; cp gpurun_out/r3p/pmc_$sc/summary.txt $O/pmc_${sc}_summary.txt; cp gpurun_out/r3p/pmc_$sc/pmc.json $O/pmc_$sc.json
+  cp $O/pmc_$sc.json profiles/pmc_$sc.json
   timeout -k 10 200 python3 bench.py --scene $sc --no-cpu-baseline --no-caller-path > $O/bench_$sc.json 2>> $O/bench.err
 done
 echo "pmc done" >> $O/log.txt

@@ -16,8 +16,9 @@ from lidarcast import synth  # noqa: E402
 mesh = synth.make_room(size=(4.0, 3.0, 2.5), num_boxes=4, seed=5, cell=0.04)
 ctx = lidarcast.Context(0)
 scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
-k = Indoor8LineLidarIntrinsics(vertical_res=8, horizontal_res=1024, max_range=20.0,
-                               vertical_degrees=[25.0, 15.0, 5.0, 0.0, -5.0, -15.0, -25.0, -35.0])
+# 16 lines x 1024: 256 tiles per pose, so the default launch deals every pose to the XCDs in 16 chunks (XCD striping)
+k = Indoor8LineLidarIntrinsics(vertical_res=16, horizontal_res=1024, max_range=20.0,
+                               vertical_degrees=[float(x) for x in np.linspace(25.0, -35.0, 16)])
 poses = np.stack([np.eye(4) for _ in range(4)])
 poses[:, :3, 3] = [(0.8, 1.2, 1.0), (1.6, 1.4, 1.0), (2.4, 1.6, 1.1), (3.2, 1.5, 0.9)]
 dirs = IndoorLidar(k, np.eye(4)).sensor_directions()

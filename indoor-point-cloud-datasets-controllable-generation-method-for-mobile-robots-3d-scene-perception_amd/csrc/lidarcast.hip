@@ -703,7 +703,7 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
                 }
             }
 #ifdef LRC_VARIANTS
-            if (p.force_redo) redo |= (gid % p.force_redo) == 0;      // test hook (LRC_DEBUG_FORCE_REDO=m)
+            if (p.force_redo) redo |= (((uint64_t)blockIdx.x * kTBlock + tid) % p.force_redo) == 0;   // test hook (LRC_DEBUG_FORCE_REDO=m)
 #endif
         }
     };
@@ -757,10 +757,17 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
         cx = c[0]; cy = c[1]; cz = c[2];
     } else if (p.has_center) { cx = p.cx; cy = p.cy; cz = p.cz; }
     else { cx = (double)o.x; cy = (double)o.y; cz = (double)o.z; }
-    write_back<GEN != 0>(p, gid, tid, o, d, cx, cy, cz, tbest, best_slot);
+    // the ray's index is formed again from the workgroup number (scalar arithmetic) instead of being carried through the
+    // traversal in two registers the kernel does not have (the compiler spilled them to scratch: 8 B per ray each way);
+    // the workgroup number is made opaque so that the two computations are not merged
+    uint32_t wg = blockIdx.x;
+    asm volatile("" : "+s"(wg));
+    const uint32_t tile_w = p.tile_chunk_log2 ? xcd_tile_chunked(wg, gridDim.x, p.tile_chunk_log2) : xcd_tile(wg, gridDim.x);
+    const uint64_t gid_w = (uint64_t)tile_w * kTBlock + tid;
+    write_back<GEN != 0>(p, gid_w, tid, o, d, cx, cy, cz, tbest, best_slot);
     if (STATS) {
         if (p.stats) {
-            uint32_t* q = p.stats + gid * kStatsWords;
+            uint32_t* q = p.stats + gid_w * kStatsWords;
             q[0] = st_nodes; q[1] = st_tris; q[2] = st_uni; q[3] = st_dead; q[4] = st_pad;
         }
     }

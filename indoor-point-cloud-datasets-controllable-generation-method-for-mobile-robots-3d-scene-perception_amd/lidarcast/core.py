@@ -63,7 +63,6 @@ class PinnedPool:
         # (re-entrant: dropping the last reference to a slab inside a guarded section runs _release on the spot)
         import threading
         self._lock = threading.RLock()
-        self._prefetching_classes = set()
 
     @staticmethod
     def _klass(nbytes):
@@ -107,54 +106,22 @@ class PinnedPool:
         weakref.finalize(raw, PinnedPool._release, weakref.ref(self), ptr, self.SLAB_BYTES, self._ctx)
         return raw
 
-    def _prefetch_slab(self):
-        """Page-lock the NEXT slab on a helper thread (locking pages costs ~0.15 ms per MB; the library call releases the
-        GIL): a caller that keeps every frame -- the reference's loop does -- then finds it ready."""
-        import threading
-
-        def work():
-            try:
-                ptr = self._new_block(self.SLAB_BYTES)
-            except Exception:
-                ptr = None
-            with self._lock:
-                self._spare = ptr
-                self._prefetching = False
-        with self._lock:
-            if self._prefetching or self._spare is not None:
-                return
-            self._prefetching = True
-        threading.Thread(target=work, daemon=True).start()
-
-    _spare = None
-    _prefetching = False
-
     def _take_small(self, nbytes):
         """A slice of a page-locked slab (bump allocation, 256-byte aligned).  A per-waypoint caller -- the reference's own
         loop keeps every frame it is handed -- would otherwise pay a hipHostMalloc per call; this way it pays one per
-        32 MB, and that one ahead of time on a helper thread.  A slab returns to the pool when the last array cut from
-        it is dropped."""
+        32 MB.  A slab returns to the pool when the last array cut from it is dropped.  (Locking the next slab ahead of
+        time on a helper thread was tried: the runtime serialises it with the caller's own HIP calls, nothing is gained.)"""
         n = (int(nbytes) + 255) & ~255
-        want_prefetch = False
         with self._lock:
             sl = self._slab
             if sl is not None and sl[1] + n <= self.SLAB_BYTES:
                 off = sl[1]
                 sl[1] += n
-                want_prefetch = sl[1] > self.SLAB_BYTES // 2 and self._spare is None and not self._prefetching
-                out = np.frombuffer(sl[0], dtype=np.uint8, count=max(int(nbytes), 1), offset=off)
-            else:
-                out = None
-                self._slab = None          # the old slab lives on through the arrays cut from it
-                ptr, self._spare = self._spare, None
-        if out is not None:
-            if want_prefetch:
-                self._prefetch_slab()
-            return out
+                return np.frombuffer(sl[0], dtype=np.uint8, count=max(int(nbytes), 1), offset=off)
+            self._slab = None          # the old slab lives on through the arrays cut from it
+        ptr = self._new_block(self.SLAB_BYTES)
         if ptr is None:
-            ptr = self._new_block(self.SLAB_BYTES)
-            if ptr is None:
-                return np.empty(max(int(nbytes), 1), dtype=np.uint8)
+            return np.empty(max(int(nbytes), 1), dtype=np.uint8)
         raw = self._wrap_slab(ptr)
         with self._lock:
             self._slab = [raw, n]
@@ -187,32 +154,7 @@ class PinnedPool:
                 self.allocations += 1
         raw = (C.c_uint8 * k).from_address(ptr)
         weakref.finalize(raw, PinnedPool._release, weakref.ref(self), ptr, k, self._ctx)
-        self._prefetch_block(k)
         return np.frombuffer(raw, dtype=np.uint8, count=k)
-
-    def _prefetch_block(self, k):
-        """One spare block of the size class just handed out, page-locked on a helper thread: a caller that scans scene
-        after scene and keeps the frames (the reference's batch loop does) finds the next buffer ready instead of paying
-        ~0.15 ms per MB in its scan stage.  At most one spare per class; nothing happens while a free block exists."""
-        import threading
-        with self._lock:
-            if self._free.get(k) or k in self._prefetching_classes or self.outstanding + 2 * k > self._max_out:
-                return
-            self._prefetching_classes.add(k)
-
-        def work():
-            ptr = None
-            try:
-                ptr = self._new_block(k)
-            except Exception:
-                ptr = None
-            with self._lock:
-                self._prefetching_classes.discard(k)
-                if ptr is not None:          # parked in the free list: not outstanding until taken
-                    self.outstanding -= k
-                    self._free.setdefault(k, []).append(ptr)
-                    self._free_bytes += k
-        threading.Thread(target=work, daemon=True).start()
 
     @staticmethod
     def _release(pool_ref, ptr, k, ctx):
@@ -229,18 +171,9 @@ class PinnedPool:
             ctx._lib.lrc_host_free(ctx._h, C.c_void_p(ptr))
 
     def clear(self):
-        import time
-        for _ in range(400):               # a prefetch in flight finishes first (its block must not outlive the context)
-            with self._lock:
-                if not self._prefetching and not self._prefetching_classes:
-                    break
-            time.sleep(0.005)
         with self._lock:
             self._slab = None
-            spare, self._spare = self._spare, None
-            if spare is not None:
-                self.outstanding -= self.SLAB_BYTES
-            lists = list(self._free.values()) + ([[spare]] if spare is not None else [])
+            lists = list(self._free.values())
             self._free = {}
             self._free_bytes = 0
         for lst in lists:

@@ -17,7 +17,6 @@
 //   cloud_*              the same compaction with the hit point rebuilt from (t, label) pairs (multi-GPU assembly).
 #include <hip/hip_runtime.h>
 
-#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -101,10 +100,6 @@ struct lrc_ctx {
     uint64_t* h_counts = nullptr;       // page-locked landing area of the per-pose counts and statistics (async copies
     uint64_t h_counts_cap = 0;          // need one): counts (P u64) | 4 x P doubles of per-pose statistics
     lrc::DeviceArena build_arena;       // scratch of the device scene build, reused from scene to scene
-    // ticket counters of the persistent trace launches: a ring of kTicketSets sets (8 XCDs x kTicketLists); launch n uses set
-    // n % kTicketSets and zeroes the set half a ring ahead, so no launch waits for a memset
-    uint32_t* d_tickets = nullptr;
-    std::atomic<uint32_t> ticket_seq{0};
 };
 
 struct lrc_table {            // a sensor's direction table resident in HBM (lrc_table_create)
@@ -121,7 +116,6 @@ struct lrc_scene {
     uint32_t* d_slot_prim = nullptr;
     uint32_t* d_slot_label = nullptr;
     float* d_slot_box = nullptr;      // per leaf slot the triangle's exact vertex box (lo xyz, hi xyz)
-    int persist_grid = -1;            // workgroups of a persistent trace launch (CUs x resident workgroups per CU); -1 = not asked yet
     float4* d_prim_plane = nullptr;   // per caller's triangle row: (v0, label bits), (Ng, 0): lrc_cloud_from_prims_dev
     float4* d_slot_sphere = nullptr;  // per leaf slot: centre of the triangle's box + bounding radius (sector_kernel)
     // quantised node images of the SAME tree ("32-byte nodes"): child boxes on a 15-bit grid
@@ -191,11 +185,6 @@ struct TraceParams {
     uint32_t* stats;           // STATS build only: kStatsWords counters per ray
     uint64_t rays_per_pose;
     uint64_t total;
-    // persistent launch (PERSIST kernels): the waves take their tiles from per-XCD ticket counters
-    uint32_t ntiles;           // tiles of the scan = workgroups of the one-shot launch
-    uint32_t tiles_per_pose;
-    uint32_t* tickets;         // 8 x kTicketLists counters (kTicketStride dwords apart), zero at launch
-    uint32_t* tickets_clear;   // the counter set of a later launch, zeroed by this one
     int has_center;
     double cx, cy, cz;
     double max_range;
@@ -319,15 +308,9 @@ __device__ __forceinline__ void rebuild_counts(const RebuildParams& q, uint32_t 
 // best_slot = 0xFFFFFFFF: no hit.  FILTER: apply the max_range filter (scans and casts with a centre).
 // BY_PRIM: `best_slot` is the caller's triangle ROW (sector_kernel keys rays by (t, row)); labels and the normal then
 // come from the per-row plane table instead of the per-slot arrays -- same values.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// before_stores: called when every value is computed and no store is issued yet (the persistent kernel resolves its next
-// tile there)
-// LEAN: the incident angle and the intensity are not asked for (the persistent kernel: their float64 acos would be set
-// up once per wave and held -- spilled -- across all its tiles).
-template <bool FILTER_ALWAYS, bool BY_PRIM = false, bool LEAN = false, class Hook = NoHook>
+template <bool FILTER_ALWAYS, bool BY_PRIM = false>
 __device__ __forceinline__ void write_back(const TraceParams& p, uint64_t gid, uint32_t tid, V3 o, V3 d, double cx,
-                                           double cy, double cz, float tbest, uint32_t best_slot,
-                                           Hook before_stores = Hook{}) {
+                                           double cy, double cz, float tbest, uint32_t best_slot) {
     constexpr int GEN = FILTER_ALWAYS ? 1 : 0;
     bool keep = best_slot != 0xFFFFFFFFu;
     float t_out = __builtin_inff();
@@ -362,14 +345,14 @@ __device__ __forceinline__ void write_back(const TraceParams& p, uint64_t gid, u
                 prim = p.slot_prim[best_slot];
                 label = p.slot_label[best_slot];
             }
-            if (p.out.normal3 || (!LEAN && (p.out.intensity || (p.out.incident_deg && p.incident_mode == 1)))) {
+            if (p.out.normal3 || p.out.intensity || (p.out.incident_deg && p.incident_mode == 1)) {
                 float4 c;
                 if (BY_PRIM) { const float4 g = p.prim_plane[(size_t)best_slot * 2 + 1]; c = make_float4(0.f, g.x, g.y, g.z); }
                 else c = p.tris[(size_t)best_slot * 3 + 2];
                 const float len = __builtin_sqrtf(fma_(c.w, c.w, fma_(c.z, c.z, c.y * c.y)));
                 nx = c.y / len; ny = c.z / len; nz = c.w / len;
             }
-            if (!LEAN && p.out.incident_deg) {
+            if (p.out.incident_deg) {
                 if (p.incident_mode == 1) {   // opt-in: angle between the ray and the surface normal
                     const double cs = __builtin_fabs(((double)hx * (double)nx + (double)hy * (double)ny) +
                                                      (double)hz * (double)nz);
@@ -378,14 +361,13 @@ __device__ __forceinline__ void write_back(const TraceParams& p, uint64_t gid, u
                     inc = acos(__builtin_fabs(ez / dist)) * kRadToDeg;
                 }
             }
-            if (!LEAN && p.out.intensity)      // opt-in: Lambertian return |h.n|, float32 (same FMA order as every dot product here)
+            if (p.out.intensity)      // opt-in: Lambertian return |h.n|, float32 (same FMA order as every dot product here)
                 inten = __builtin_fabsf(fma_(hz, nz, fma_(hy, ny, hx * nx)));
             if (!p.out.normal3) { nx = ny = nz = 0.f; }
         } else {
             px = py = pz = 0.f;
         }
     }
-    before_stores();
     if (p.out.tile_count) {   // kept rays of this wave's 64 consecutive outputs (feeds lrc_compact_dev)
         const unsigned long long m = __ballot(keep);
         if ((tid & 63u) == 0) p.out.tile_count[gid >> 6] = (uint32_t)__popcll(m);
@@ -397,32 +379,11 @@ __device__ __forceinline__ void write_back(const TraceParams& p, uint64_t gid, u
     if (p.out.point3) { float* q = p.out.point3 + gid * 3; q[0] = px; q[1] = py; q[2] = pz; }
     if (p.out.sem) p.out.sem[gid] = (uint16_t)(label & 0xFFFFu);
     if (p.out.ins) p.out.ins[gid] = (uint16_t)(label >> 16);
-    if (!LEAN && p.out.incident_deg) p.out.incident_deg[gid] = inc;
-    if (!LEAN && p.out.intensity) p.out.intensity[gid] = inten;
+    if (p.out.incident_deg) p.out.incident_deg[gid] = inc;
+    if (p.out.intensity) p.out.intensity[gid] = inten;
 
 }
 
-// Measurement build (-DLRC_WAVE_CLOCK, tools/wave_timeline.py): every wave leaves its start / end on the 100 MHz constant
-// clock, its XCD and its hardware slot in lanes 0..3 of the (otherwise unused) intensity column.  The product build
-// compiles both helpers to nothing.
-#ifdef LRC_WAVE_CLOCK
-__device__ __forceinline__ uint64_t wave_clock() { return __builtin_amdgcn_s_memrealtime(); }
-__device__ __forceinline__ void wave_clock_store(float* col, uint64_t gid, uint32_t tid, uint64_t t0) {
-    if (col && tid < 4) {
-        const uint64_t t1 = __builtin_amdgcn_s_memrealtime();
-        const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20), hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        col[gid] = __uint_as_float(tid == 0 ? (uint32_t)t0 : tid == 1 ? (uint32_t)t1 : tid == 2 ? xcc : hw);
-    }
-}
-#else
-__device__ __forceinline__ uint64_t wave_clock() { return 0; }
-__device__ __forceinline__ void wave_clock_store(float*, uint64_t, uint32_t, uint64_t) {}
-#endif
-
-constexpr int kTicketSets = 64;      // launches whose ticket counters can be live at once (x 2)
-constexpr int kTicketLists = 16;     // counters per XCD
-constexpr int kTicketStride = 16;    // dwords between two counters: one 64-byte line each
-constexpr int kTicketSetWords = 8 * kTicketLists * kTicketStride;
 constexpr int kStatsWords = 5;   // node steps, triangle tests, wave-uniform node steps, dead node steps, pad-clause rejections
 
 template <int I> struct IntTag { static constexpr int value = I; };
@@ -431,57 +392,21 @@ template <int I> struct IntTag { static constexpr int value = I; };
 // QN: 1 = walk the quantised node images (32-byte nodes for the per-lane fetches), 2 = walk their
 //     four-wide collapse (64-byte nodes, half the steps); a wave with a ray outside the bound the quantisation margin is
 //     proven for walks the float32 world-space nodes instead
-// PERSIST (GEN = 1, rays_per_pose % 64 == 0 only): as many workgroups as the chip holds at once; a wave that has
-// finished a tile takes the next one from its XCD's ticket counter (and, once that list is empty, from the other XCDs'),
-// so the order of the tiles on every XCD is the one-shot launch's, but a wave slot does not sit empty while the finished
-// wave's stores are acknowledged and a new workgroup is set up (7 % of the slot time, profiles/r03_wave_timeline.txt):
-// the next tile's direction is fetched before the stores are issued and its pose through the scalar cache, so the first
-// vector load the next tile WAITS for is deep in its traversal.
-// PERSIST = 1: the tiles in XCD-striped order (tile_chunk_log2 != 0), 2: in eight contiguous ranges -- fixed at compile time
-// there, so that the choice is not one more wave-uniform flag held across the tiles.
-template <int GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false, int QN = 0, int PERSIST = 0>
+template <int GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false, int QN = 0>
 __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) void trace_kernel(const TraceParams p) {
-    static_assert(!PERSIST || GEN == 1, "the persistent launch is for pose-batched scans");
     extern __shared__ int s_stack[];   // [stack depth][kTBlock]: one column per lane, conflict free
     const uint32_t tid = threadIdx.x;
-    const uint32_t ngrid = PERSIST ? p.ntiles : gridDim.x;      // workgroups of the one-shot launch: what the tile order is defined on
-    auto tile_of = [&](uint32_t b) {
-        if (PERSIST == 1) return xcd_tile_chunked(b, ngrid, p.tile_chunk_log2);
-        if (PERSIST == 2) return xcd_tile(b, ngrid);
-        return p.tile_chunk_log2 ? xcd_tile_chunked(b, ngrid, p.tile_chunk_log2) : xcd_tile(b, ngrid);
-    };
-    uint32_t blk = blockIdx.x;         // the workgroup number of the one-shot launch this wave is working for
-    uint32_t xcc = 0;
-    double pre_a = 0.0, pre_b = 0.0, pre_c = 0.0;      // PERSIST: the direction of this lane's ray in the tile `blk`
-    if (PERSIST) {
-        xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // XCC_ID
-        if (blockIdx.x == 0) { for (uint32_t c = tid; c < 8u * kTicketLists; c += kTBlock) p.tickets_clear[c * kTicketStride] = 0u; }
-        const uint32_t t0 = tile_of(blk);
-        const double* dv = p.dirs3 + ((size_t)(t0 % p.tiles_per_pose) * kTBlock + tid) * 3;
-        pre_a = dv[0]; pre_b = dv[1]; pre_c = dv[2];
-    }
-  for (;;) {
-    const uint32_t tile = tile_of(blk);
+    const uint32_t tile = p.tile_chunk_log2 ? xcd_tile_chunked(blockIdx.x, gridDim.x, p.tile_chunk_log2)
+                                            : xcd_tile(blockIdx.x, gridDim.x);
     const uint64_t gid = (uint64_t)tile * kTBlock + tid;
-    if (!PERSIST) { if (gid >= p.total) return; }
-    const uint64_t wave_t0 = wave_clock();     // measurement build only (tools/wave_timeline.py); nothing otherwise
+    if (gid >= p.total) return;
 
     // ---- the ray ----
     V3 o, d;
     double cx, cy, cz;
     bool live = true;          // false: not cast at all (dropped by the sensor, or a non-finite ray)
     uint32_t pose32 = 0;
-    if (PERSIST) {
-        // the tile lies in one pose: its matrix comes through the scalar cache, the direction is already here
-        typedef __attribute__((address_space(4))) const double cdouble;
-        pose32 = tile / p.tiles_per_pose;
-        cdouble* M = (cdouble*)(p.poses16 + (size_t)pose32 * 16);
-        d.x = (float)lrcdev::dgemm_row(pre_a, pre_b, pre_c, M[0], M[1], M[2]);
-        d.y = (float)lrcdev::dgemm_row(pre_a, pre_b, pre_c, M[4], M[5], M[6]);
-        d.z = (float)lrcdev::dgemm_row(pre_a, pre_b, pre_c, M[8], M[9], M[10]);
-        cx = M[3]; cy = M[7]; cz = M[11];
-        o.x = (float)cx; o.y = (float)cy; o.z = (float)cz;
-    } else if (GEN == 1) {
+    if (GEN == 1) {
         const uint64_t pose = gid / p.rays_per_pose;
         const uint64_t i = gid - pose * p.rays_per_pose;
         gen_ray(p.poses16, p.dirs3, pose, i, o, d, cx, cy, cz);
@@ -554,8 +479,6 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
         }
         int sp = 0;
         int ref = 0;   // root
-        auto push = [&](int r) { s_stack[sp * kTBlock + tid] = r; ++sp; };
-        auto pop = [&]() { --sp; return s_stack[sp * kTBlock + tid]; };
         // descend into the nearer hit child, push the other; nothing hit -> pop, or (stack empty) continue with the
         // empty leaf so that the outer loop ends
         auto choose = [&](float n0, float f0, float n1, float f1, int r0, int r1) {
@@ -564,7 +487,8 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
             const bool h1 = (n1 <= f1) & (n1 <= tbest);
             if (h0 & h1) {
                 const bool first0 = n0 <= n1;
-                push(first0 ? r1 : r0);
+                s_stack[sp * kTBlock + tid] = first0 ? r1 : r0;
+                ++sp;
                 ref = first0 ? r0 : r1;
             } else if (h0) {
                 ref = r0;
@@ -575,7 +499,8 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
                 ref = ~0;   // empty leaf
             } else {
                 if (STATS) st_dead += 1u;
-                ref = pop();
+                --sp;
+                ref = s_stack[sp * kTBlock + tid];
             }
         };
         // one inner-node step on a float32 node (world space, or the normalised image on the scalar path)
@@ -753,14 +678,16 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
                     // that this lane stays busy while its neighbours are still in inner nodes
                     if ((ref < 0) & (ref != ~0) & (pending == ~0) & (sp > 0)) {
                         pending = ref;
-                        ref = pop();
+                        --sp;
+                        ref = s_stack[sp * kTBlock + tid];
                     }
                 }
             }
             if (SPEC) leaf(pending);
             leaf(ref);
             if (sp == 0) break;
-            ref = pop();
+            --sp;
+            ref = s_stack[sp * kTBlock + tid];
         }
         if (!INLINE_CLAUSE) {
             if (best_slot != 0xFFFFFFFFu) {       // the box clause of the closest candidate, in world coordinates
@@ -789,9 +716,8 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
                 return !(__builtin_fabsf(oa - base) <= lrc::kQnodeNearBase * W) | !(__builtin_fabsf(oa) <= lrc::kQnodeNearOrigin * W) |
                        !(__builtin_fabsf(da) <= 0x1p60f);
             };
-            float w0 = p.qW[0], w1 = p.qW[1], w2 = p.qW[2];
-            if (PERSIST) asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2));    // per tile: the bounds below are not to be held across tiles
-            const bool far = live & (far1(o.x, d.x, p.qbase[0], w0) | far1(o.y, d.y, p.qbase[1], w1) | far1(o.z, d.z, p.qbase[2], w2));
+            const bool far = live & (far1(o.x, d.x, p.qbase[0], p.qW[0]) | far1(o.y, d.y, p.qbase[1], p.qW[1]) |
+                                     far1(o.z, d.z, p.qbase[2], p.qW[2]));
             const uint32_t oct = sign_octant(d);
             // octant of the first ACTIVE lane (which may be a ray that is not cast: the wave then merely takes the float32
             // nodes; results do not depend on the choice)
@@ -819,13 +745,7 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
     }
 
     // ---- fused write-back ----
-    if (PERSIST) {
-        typedef __attribute__((address_space(4))) const double cdouble;
-        uint32_t ps = tile_of(blk) / p.tiles_per_pose;
-        asm volatile("" : "+s"(ps));        // formed again (scalar arithmetic) rather than held through the traversal
-        cdouble* M = (cdouble*)(p.poses16 + (size_t)ps * 16);
-        cx = M[3]; cy = M[7]; cz = M[11];
-    } else if (GEN != 0) {
+    if (GEN != 0) {
         // the range-filter centre (the pose's translation, float64) is fetched again here instead of being held in six
         // registers through the traversal; the pointer is made opaque so that the fetch is not merged with gen_ray's
         const double* M = p.poses16;
@@ -840,60 +760,18 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
     // the ray's index is formed again from the workgroup number (scalar arithmetic) instead of being carried through the
     // traversal in two registers the kernel does not have (the compiler spilled them to scratch: 8 B per ray each way);
     // the workgroup number is made opaque so that the two computations are not merged
-    uint32_t wg = blk;
+    uint32_t wg = blockIdx.x;
     asm volatile("" : "+s"(wg));
-    const uint32_t tile_w = tile_of(wg);
+    const uint32_t tile_w = p.tile_chunk_log2 ? xcd_tile_chunked(wg, gridDim.x, p.tile_chunk_log2) : xcd_tile(wg, gridDim.x);
     const uint64_t gid_w = (uint64_t)tile_w * kTBlock + tid;
-    if (PERSIST) {
-        // the next tile: a ticket of this XCD's counter, asked for now and looked at when the outputs are computed
-        // Workgroup 8 j + x of the one-shot launch belongs to XCD x; the launch itself handed out j < j0 = ceil((gridDim.x - x) / 8).
-        // The rest of an XCD's list is dealt to kTicketLists counters (j % kTicketLists), each on its own cache line: a
-        // device-wide atomic on ONE address completes every ~94 ns (measured), 65 536 tiles through 8 counters took 1.4 ms.
-        // A wave draws from its home list (its launch slot % kTicketLists), then from the next two, then ends: a list is
-        // emptied by its home waves at the latest, and all lists run dry together.
-        uint32_t ticket = 0, xc = xcc, ls = (blockIdx.x >> 3) % (uint32_t)kTicketLists;
-        asm volatile("" : "+s"(xc), "+s"(ls));   // per tile: no counter address is to be held across the traversal
-        if (tid == 0) ticket = atomicAdd(p.tickets + (xc * kTicketLists + ls) * kTicketStride, 1u);
-        uint32_t next = 0xFFFFFFFFu;
-        write_back<true, false, true>(p, gid_w, tid, o, d, cx, cy, cz, tbest, best_slot, [&]() {
-            uint32_t nb = 0xFFFFFFFFu;
-            if (tid == 0) {
-                const uint32_t j0 = (gridDim.x + 7u - xc) >> 3;
-#pragma unroll 1
-                for (uint32_t k = 0; k < 3u; ++k) {
-                    const uint32_t l = (ls + k) % (uint32_t)kTicketLists;
-                    if (k) ticket = atomicAdd(p.tickets + (xc * kTicketLists + l) * kTicketStride, 1u);
-                    // the list's first member at or after j0, then every kTicketLists-th
-                    const uint32_t first = j0 + (l + (uint32_t)kTicketLists - j0 % (uint32_t)kTicketLists) % (uint32_t)kTicketLists;
-                    const uint64_t b = ((uint64_t)first + (uint64_t)ticket * kTicketLists) * 8u + xc;
-                    if (b < p.ntiles) { nb = (uint32_t)b; break; }
-                }
-            }
-            next = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
-            // its direction, fetched before this tile's stores are issued (unconditionally -- entry 0 when there is no next
-            // tile -- so that the old one is dead; the lane number is made opaque so that nothing derived from it is held
-            // across the traversal)
-            uint32_t lane = tid;
-            asm volatile("" : "+v"(lane));
-            const uint32_t nt = next != 0xFFFFFFFFu ? tile_of(next) % p.tiles_per_pose : 0u;
-            const double* dv = p.dirs3 + ((size_t)nt * kTBlock + lane) * 3;
-            pre_a = dv[0]; pre_b = dv[1]; pre_c = dv[2];
-        });
-        wave_clock_store(p.out.intensity, gid_w, tid, wave_t0);
-        if (next == 0xFFFFFFFFu) return;
-        blk = next;
-    } else {
-        write_back<GEN != 0>(p, gid_w, tid, o, d, cx, cy, cz, tbest, best_slot);
-        if (STATS) {
-            if (p.stats) {
-                uint32_t* q = p.stats + gid_w * kStatsWords;
-                q[0] = st_nodes; q[1] = st_tris; q[2] = st_uni; q[3] = st_dead; q[4] = st_pad;
-            }
+    write_back<GEN != 0>(p, gid_w, tid, o, d, cx, cy, cz, tbest, best_slot);
+    if (STATS) {
+        if (p.stats) {
+            uint32_t* q = p.stats + gid_w * kStatsWords;
+            q[0] = st_nodes; q[1] = st_tris; q[2] = st_uni; q[3] = st_dead; q[4] = st_pad;
         }
-        wave_clock_store(p.out.intensity, gid_w, tid, wave_t0);
-        return;
     }
-  }
+
 }
 
 #ifdef LRC_VARIANTS
@@ -1364,12 +1242,6 @@ int lrc_ctx_create(int device, lrc_ctx** out_ctx) {
     lrc_ctx* c = new (std::nothrow) lrc_ctx();
     if (!c) return fail(LRC_ERR_OOM, "lrc_ctx_create: out of host memory");
     c->device = device;
-    if (hipMalloc((void**)&c->d_tickets, (size_t)kTicketSets * kTicketSetWords * sizeof(uint32_t)) != hipSuccess ||
-        hipMemset(c->d_tickets, 0, (size_t)kTicketSets * kTicketSetWords * sizeof(uint32_t)) != hipSuccess) {
-        if (c->d_tickets) (void)hipFree(c->d_tickets);
-        delete c;
-        return fail(LRC_ERR_OOM, "lrc_ctx_create: out of device memory");
-    }
     *out_ctx = c;
     return LRC_OK;
 }
@@ -1380,7 +1252,6 @@ int lrc_ctx_destroy(lrc_ctx* ctx) {
     for (int k = 0; k < kPoolSlots; ++k)
         if (ctx->pool[k]) (void)hipFree(ctx->pool[k]);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
-    if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
     lrc::arena_release(&ctx->build_arena);
     if (ctx->s_compute) (void)hipStreamDestroy(ctx->s_compute);
     if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
@@ -1810,15 +1681,6 @@ static int launch_trace_lab(lrc_scene* s, TraceParams& p, int gen, hipStream_t s
 }
 #endif   // LRC_VARIANTS
 
-static bool persist_enabled() {
-#ifdef LRC_VARIANTS
-    static const int on = env_int("LRC_PERSIST", 1);     // A/B knob of the laboratory build: 0 = one workgroup per tile
-    return on != 0;
-#else
-    return true;
-#endif
-}
-
 // One launch of the trace kernel over p.total rays.  gen: 0 explicit rays, 1 pose x direction table, 2 pose x scan angles,
 // 3 a grid scan (lrc_scan_grid_*: the per-ray kernel here; the packet kernel in the laboratory build).
 static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, bool stats = false) {
@@ -1883,33 +1745,6 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
     }
 #endif
     if (gen == 3) gen = 1;
-    // A pose-batched scan that needs more workgroups than the chip holds at once is launched persistently: as many waves
-    // as fit, each taking tile after tile from its XCD's ticket counter (trace_kernel<..., PERSIST>).
-    if (gen == 1 && !stats && qn && p.rays_per_pose % kTBlock == 0 && p.rays_per_pose / kTBlock <= 0xFFFFFFFFull &&
-        !p.out.incident_deg && !p.out.intensity && persist_enabled()) {
-        if (s->persist_grid < 0) {
-            int blocks = 0, cus = 0;
-            LRC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trace_kernel<1, kLeafW, true, false, false, 1, 1>, kTBlock, lds));
-            LRC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device));
-            s->persist_grid = blocks * cus;
-        }
-        if (s->persist_grid > 0 && nblk > (uint64_t)s->persist_grid) {
-            lrc_ctx* c = s->ctx;
-            const uint32_t set = c->ticket_seq.fetch_add(1u) % (uint32_t)kTicketSets;
-            p.ntiles = (uint32_t)nblk;
-            p.tiles_per_pose = (uint32_t)(p.rays_per_pose / kTBlock);
-            p.tickets = c->d_tickets + (size_t)set * kTicketSetWords;
-            p.tickets_clear = c->d_tickets + (size_t)((set + kTicketSets / 2) % kTicketSets) * kTicketSetWords;
-            if (p.tile_chunk_log2)
-                hipLaunchKernelGGL((trace_kernel<1, kLeafW, true, false, false, 1, 1>), dim3((uint32_t)s->persist_grid), dim3(kTBlock), lds, st, p);
-            else
-                hipLaunchKernelGGL((trace_kernel<1, kLeafW, true, false, false, 1, 2>), dim3((uint32_t)s->persist_grid), dim3(kTBlock), lds, st, p);
-            LRC_HIP(hipGetLastError());
-            s->launches += 1;
-            s->rays += p.total;
-            return LRC_OK;
-        }
-    }
 #define LRC_LAUNCH(G, S, Q) \
     hipLaunchKernelGGL((trace_kernel<G, kLeafW, true, false, S, Q>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p)
     if (stats) {   // per-ray traversal counters (lrc_debug_scan_stats)

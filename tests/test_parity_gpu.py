@@ -1029,7 +1029,7 @@ def test_kernel_variants_are_bit_identical():
     split forced through the median fallback, on float32 nodes and on forced quantised images; then the laboratory build
     (-DLRC_VARIANTS, liblidarcast_lab.so through LRC_LIB): the packet kernel behind the grid entry point (on by default
     there) and with it off, the workgroup -> tile order (XCD striping, the default for this scan, against contiguous ranges
-    and another chunk size), the persistent launch of a scan of 10 240 tiles against one workgroup per tile, scalar fetch off, one triangle per leaf round trip, speculative postponement, private refill,
+    and another chunk size), scalar fetch off, one triangle per leaf round trip, speculative postponement, private refill,
     four-wide nodes, and every third / every ray sent through the redo route (the route a ray takes when its closest
     candidate fails the box clause, which no input so far has made happen), on quantised and on float32 nodes."""
     import subprocess
@@ -1047,8 +1047,6 @@ def test_kernel_variants_are_bit_identical():
                 "lab_default": lab, "lab_no_packet_kernel": dict(lab, LRC_SECTOR="0"),
                 "contiguous_tile_ranges": dict(lab, LRC_SECTOR="0", LRC_TILE_CHUNK="-1"),
                 "tile_chunks_of_32": dict(lab, LRC_SECTOR="0", LRC_TILE_CHUNK="32"),
-                "one_workgroup_per_tile": dict(lab, LRC_SECTOR="0", LRC_PERSIST="0"),
-                "one_workgroup_per_tile_contiguous_ranges": dict(lab, LRC_SECTOR="0", LRC_PERSIST="0", LRC_TILE_CHUNK="-1"),
                 "no_scalar_fetch": dict(lab, LRC_UNIFORM="0"), "leaf_singles": dict(lab, LRC_LEAFW="1"),
                 "speculative": dict(lab, LRC_SPEC="1"), "speculative_leaf_singles": dict(lab, LRC_SPEC="1", LRC_LEAFW="1"),
                 "refill_2": dict(lab, LRC_REFILL="2"),

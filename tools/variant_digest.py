@@ -35,8 +35,7 @@ scene2 = lidarcast.Scene(ctx, soup.reshape(-1, 3), np.arange(9000).reshape(-1, 3
 o = rng.uniform(-3, 3, (20000, 3))
 d = rng.normal(size=(20000, 3))
 out2 = scene2.cast(np.concatenate([o, d], 1).astype(np.float32))
-# a scan of more tiles than the chip holds waves (16 x 1024 x 40 poses = 10 240 tiles): the product library launches it
-# persistently (waves take tile after tile from ticket counters); LRC_PERSIST=0 in the laboratory build = one workgroup per tile
+# a scan of more tiles than the chip holds waves at once (16 x 1024 x 40 poses = 10 240 tiles against 8 192 wave slots)
 many = np.stack([np.eye(4) for _ in range(40)])
 many[:, :3, 3] = np.stack([np.linspace(0.6, 3.4, 40), np.linspace(1.0, 2.0, 40), np.full(40, 1.0)], 1)
 out3 = scene.scan_poses(many, dirs, k.max_range, want=("t", "prim", "normal3", "point3", "sem", "ins"))

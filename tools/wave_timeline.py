@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """tools/wave_timeline.py [scene] [poses] -- when the waves of ONE trace launch start and end (C3 sensor).
 
-Needs a library built with -DLRC_WAVE_CLOCK (tools/build_variant.sh waveclock -DLRC_WAVE_CLOCK; LRC_LIB=...): every wave
-stamps s_memrealtime (100 MHz) at its first and last instruction and leaves both, with its XCD, in the intensity column.
+Needs a measurement build of the library (the product kernel carries no measurement code):
+    git apply tools/wave_clock.patch && tools/build_variant.sh waveclock && git apply -R tools/wave_clock.patch
+    LRC_LIB=$PWD/build_variants/waveclock.so python3 tools/wave_timeline.py
+In it every wave stamps s_memrealtime (100 MHz) at its first and last instruction and leaves both, with its XCD and its
+hardware slot, in the intensity column.
 Prints the distribution of wave lifetimes, the number of resident waves over the launch and what the ramp and the tail cost
 against a launch that kept the steady-state rate from the first to the last nanosecond."""
 import os

@@ -310,7 +310,7 @@ def create_simulator_from_config(config_path: Optional[str] = None) -> S3DISSimu
 
 def run_scene_batch(scenes, trajectories, sensor=None, config: Optional[Dict[str, Any]] = None,
                     use_dense_lidar: bool = False, use_blk2go: bool = False, output_base_dir=None,
-                    process_group=None, skip_existing: bool = True) -> Dict[str, Any]:
+                    process_group=None, skip_existing: bool = True, on_scene=None) -> Dict[str, Any]:
     """Several scenes through one simulator, the job of the reference's batch loop (s3dis_simulator.py:594-726:
     per scene load -> trajectory -> run_simulation -> save_results, failures collected, finished scenes skipped) as
     a function instead of a hard-coded ``main``.
@@ -320,6 +320,9 @@ def run_scene_batch(scenes, trajectories, sensor=None, config: Optional[Dict[str
     sensor        optional intrinsics record replacing the simulator's default (e.g. a 32-line x 2048 sweep)
     output_base_dir  results of scene ``name`` go to <dir>/<name>; a scene whose labelled cloud and statistics
                   file exist is skipped (the reference's resume rule, :637-648)
+    on_scene      optional callable (name, sim_scene): called when a scene is done (after its files are written); the scene
+                  is then NOT kept in the report, as the reference's loop keeps none (:661-700) -- its frames' page-locked
+                  buffers go back to the pool and the next scene's scan reuses them instead of locking fresh pages
     Inside a torch.distributed job the scenes are dealt round-robin to the ranks (each scene is one rank's work, its
     trajectory is not sharded again) and the per-scene summaries are gathered; ``sim_scene`` objects stay on the
     rank that produced them.  Returns {"scenes": {name: {...}}, "failed": [...], "skipped": [...], "total_rays",
@@ -362,6 +365,10 @@ def run_scene_batch(scenes, trajectories, sensor=None, config: Optional[Dict[str
                 sim.save_results(sim_scene, out_dir, waypoints)
             done[name] = {"sim_scene": sim_scene, "frames": len(sim_scene.frames), "rays": len(waypoints) * rays_per_pose,
                           "points": int(sim_scene.get_total_points()), "seconds": dt, "build_seconds": t0 - tb}
+            if on_scene is not None:
+                on_scene(name, sim_scene)
+                done[name]["sim_scene"] = None
+            del sim_scene
         except Exception as e:                                       # noqa: BLE001 - the reference collects and goes on
             failed.append((name, str(e)))
     if dist is not None:

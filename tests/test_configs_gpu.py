@@ -235,11 +235,12 @@ def test_c5_six_scenes_full_size(engine):
     sensor = bench.c3_sensor()
     names = list(synth.SCENES)
     meshes = {n: synth.make_scene(n) for n in names}
-    report = run_scene_batch([(n, meshes[n]) for n in names], {n: _line_poses(n, 64) for n in names},
-                             sensor=sensor, config={"raycast_engine": {"use_gpu": True}})
-    assert set(report["scenes"]) == set(names) and report["total_rays"] == 6 * 64 * 65536
-    for name in names:
-        mesh, sim = meshes[name], report["scenes"][name]["sim_scene"]
+    checked = []
+
+    def check_scene(name, sim):
+        # called per scene, which is then released (as the reference's batch loop keeps no scene): the next scene's frames
+        # reuse its page-locked buffers
+        mesh = meshes[name]
         poses = _line_poses(name, 64)
         assert len(sim.frames) == 64
         counts = np.array([len(f.points) for f in sim.frames])
@@ -264,6 +265,12 @@ def test_c5_six_scenes_full_size(engine):
         cd = float(np.mean(min_distances(mine, ref, engine.ctx)) + np.mean(min_distances(ref, mine, engine.ctx)))
         assert cd == 0.0, (name, cd)
         om.free()
+        checked.append(name)
+
+    report = run_scene_batch([(n, meshes[n]) for n in names], {n: _line_poses(n, 64) for n in names},
+                             sensor=sensor, config={"raycast_engine": {"use_gpu": True}}, on_scene=check_scene)
+    assert set(report["scenes"]) == set(names) and report["total_rays"] == 6 * 64 * 65536 and checked == names
+    assert all(report["scenes"][n]["sim_scene"] is None and report["scenes"][n]["frames"] == 64 for n in names)
     print("\n[C5]", {k: v for k, v in report.items() if k != "scenes"})
     assert report["rays_per_s"] > 2e7
 

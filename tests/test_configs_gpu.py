@@ -272,6 +272,8 @@ def test_c5_six_scenes_full_size(engine):
     assert set(report["scenes"]) == set(names) and report["total_rays"] == 6 * 64 * 65536 and checked == names
     assert all(report["scenes"][n]["sim_scene"] is None and report["scenes"][n]["frames"] == 64 for n in names)
     print("\n[C5]", {k: v for k, v in report.items() if k != "scenes"})
+    print("[C5] per scene, scan + build ms (the first scene's scan page-locks the frame buffers the others reuse):",
+          " ".join(f"{n}:{v['seconds'] * 1e3:.1f}+{v['build_seconds'] * 1e3:.1f}" for n, v in report["scenes"].items()))
     assert report["rays_per_s"] > 2e7
 
 

@@ -1142,6 +1142,39 @@ def test_device_build_equals_host_build(ctx):
         lidarcast.Scene(ctx, bad, room.triangles)
 
 
+def test_device_build_equals_host_build_on_random_meshes(ctx):
+    """The same comparison on 32 seeded random meshes whose shapes stress the builder differently: uniform soups, one
+    dense cluster with a few far outliers (bins nearly empty, median fallbacks), grid-aligned quads (many equal centroids,
+    equal costs: the first-minimum rule decides), long slivers (boxes that overlap along one axis), each with a random
+    size, leaf size and depth slack."""
+    from lidarcast.synth import TriangleMesh
+    for seed in range(32):
+        rng = np.random.default_rng(1000 + seed)
+        nt = int(rng.choice([rng.integers(5, 70), rng.integers(60, 1100), rng.integers(1000, 6000)]))
+        style = seed % 4
+        if style == 0:
+            c = rng.uniform(-3, 3, (nt, 1, 3))
+            tri = c + rng.normal(scale=0.3, size=(nt, 3, 3))
+        elif style == 1:
+            c = rng.normal(scale=0.01, size=(nt, 1, 3))
+            far = rng.random(nt) < 0.02
+            c[far] += rng.uniform(-50, 50, (int(far.sum()), 1, 3))
+            tri = c + rng.normal(scale=0.002, size=(nt, 3, 3))
+        elif style == 2:
+            g = int(np.ceil(np.sqrt(nt / 2)))
+            ij = np.stack(np.meshgrid(np.arange(g), np.arange(g), indexing="ij"), -1).reshape(-1, 2)[: (nt + 1) // 2]
+            a = np.concatenate([ij * 0.25, np.zeros((len(ij), 1))], 1)
+            q = np.stack([a, a + [0.25, 0, 0], a + [0.25, 0.25, 0], a, a + [0.25, 0.25, 0], a + [0, 0.25, 0]], 1).reshape(-1, 3, 3)
+            tri = q[:nt]
+        else:
+            c = rng.uniform(-2, 2, (nt, 1, 3))
+            d = rng.normal(size=(nt, 1, 3)) * rng.uniform(0.5, 4.0, (nt, 1, 1))
+            tri = c + np.concatenate([np.zeros((nt, 1, 3)), d, d + rng.normal(scale=0.01, size=(nt, 1, 3))], 1)
+        mesh = TriangleMesh(np.ascontiguousarray(tri, dtype=np.float64).reshape(-1, 3), np.arange(3 * len(tri)).reshape(-1, 3))
+        env = {"LRC_MAX_LEAF": int(rng.integers(1, 5)), "LRC_DEPTH_SLACK": int(rng.integers(0, 3))}
+        _assert_same_scene(*_build_both(ctx, mesh, **env), f"random mesh {seed}: style {style}, T={len(tri)}, {env}")
+
+
 def test_device_build_full_size_and_device_resident_mesh(ctx):
     """BASELINE-size scenes: device build == host build byte for byte; a mesh handed over in HBM (lrc_scene_create_dev)
     gives the same scene again; the build stays inside its time budget (T = 605 k resident in <= 10 ms)."""

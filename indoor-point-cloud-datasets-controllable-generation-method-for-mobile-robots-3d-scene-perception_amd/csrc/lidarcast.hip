@@ -2376,6 +2376,30 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
     }
     // chunks only pay when there is enough to overlap, and need pose boundaries on 64-ray tiles (fused keep counts)
     uint64_t chunks = (P * N >= (1u << 20) && N % 64 == 0) ? (P < 4 ? P : 4) : 1;
+    // Graded chunks: an eighth of the poses, then up to the half, then the rest.  The transfer of the rows is the longest
+    // stage (67 MB at 50-56 GB/s for C3): it starts as soon as a few poses are traced, and the later, larger chunks are ready
+    // before the copy engine asks for them (C3: 1.48 ms against 1.53 for four equal chunks; tools/chunk_scheme_sweep.sh,
+    // profiles/r03_chunk_schemes.txt).  Equal chunks for short trajectories.
+    bool graded = chunks == 4 && P >= 8;
+    uint32_t ends32[8] = {4, 16, 32, 32, 32, 32, 32, 32};       // chunk ends in 32nds of the trajectory
+    if (graded) chunks = 3;
+#ifdef LRC_VARIANTS
+    {   // A/B knob: LRC_CHUNK_SCHEME = "a,b,...,32" chunk ends in 32nds; "0" = four equal chunks
+        const char* e = std::getenv("LRC_CHUNK_SCHEME");
+        if (e && graded) {
+            if (e[0] == '0') { graded = false; chunks = 4; }
+            else {
+                uint64_t k = 0;
+                for (const char* q = e; *q && k < 8; ++k) { ends32[k] = (uint32_t)std::strtoul(q, (char**)&q, 10); if (*q == ',') ++q; }
+                if (k && ends32[k - 1] == 32) chunks = k;
+            }
+        }
+    }
+#endif
+    auto chunk_end = [&](uint64_t c) -> uint64_t {
+        if (!graded) return P * (c + 1) / chunks;
+        return c + 1 == chunks ? P : P * ends32[c] / 32;
+    };
     const float* noise = p.range_noise ? p.range_noise : s->opts.range_noise;   // staged in HBM by NoiseStage
     // (the callers enqueue their input copies on the compute stream: nothing to wait for here)
     const uint64_t n_all = P * N;
@@ -2436,7 +2460,7 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
     }
     uint64_t p0 = 0;
     for (uint64_t c = 0; c < chunks; ++c) {
-        const uint64_t p1 = P * (c + 1) / chunks, np_ = p1 - p0, r0 = p0 * N;
+        const uint64_t p1 = chunk_end(c), np_ = p1 - p0, r0 = p0 * N;
         TraceParams q = p;
         q.poses16 = p.poses16 + p0 * 16;
         if (q.angles2) q.angles2 = p.angles2 + r0 * 2;
@@ -2502,7 +2526,7 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
     int status = LRC_OK;
     p0 = 0;
     for (uint64_t c = 0; c < chunks; ++c) {
-        const uint64_t p1 = P * (c + 1) / chunks, r0 = p0 * N;
+        const uint64_t p1 = chunk_end(c), r0 = p0 * N;
         LRC_HIP(hipEventSynchronize(ctx->ev_chunk[c]));
         uint64_t Kc = 0;
         for (uint64_t k = p0; k < p1; ++k) { out->counts[k] = ctx->h_counts[k]; Kc += ctx->h_counts[k]; }

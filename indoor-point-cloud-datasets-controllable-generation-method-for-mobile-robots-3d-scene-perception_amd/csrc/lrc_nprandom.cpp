@@ -10,13 +10,20 @@
 //   normal    polar method: x1 = 2u - 1, x2 = 2u' - 1, r2 = x1^2 + x2^2, rejected while r2 >= 1 or r2 == 0;
 //             f = sqrt(-2 log(r2) / r2); returns f * x2 and caches f * x1 for the next call
 //             (legacy-distributions.c: legacy_gauss); normal(loc, scale) = loc + scale * gauss
-// Only the word stream is sequential.  An attempt of the polar method consumes exactly two uniforms, so where a pose's
-// normals end is known after a cheap, vectorisable pass over r2 alone (the producer thread); the expensive part -- log,
-// sqrt, division per accepted attempt, with THIS process's libm, as numpy calls it -- is done pose by pose on worker
-// threads while the producer is already generating the next pose's words.
+// Only the word stream is sequential.  An attempt of the polar method consumes exactly two uniforms = four words, and with
+// an even number of normals and of uniforms per pose every attempt of every pose starts on a multiple of four words from
+// the call's first word.  The streaming path (scan_streaming) therefore splits the work three ways:
+//   * ONE generator thread produces tempered words into 1 MiB chunks and does nothing else (0.4 ns per word);
+//   * worker threads compute, per chunk, for EVERY aligned group of four words whether it would be an accepted attempt
+//     (a quarter of the groups turn out to be uniforms: their flags are never looked at) and how many a chunk holds;
+//   * the calling thread walks the counts to find where each pose's normals end (whole chunks by their count, the last
+//     one by its flags), and hands the pose -- log, sqrt, division per accepted attempt, with THIS process's libm, as
+//     numpy calls it, then the uniforms -- to the workers.
+// Odd counts or a cached normal at entry take the sequential path (scan_sequential: the acceptance pass on the producer).
 // Pinned by tests/test_nprandom.py (-m "not gpu") against numpy itself, and through the frames by the G3 goldens.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -191,14 +198,290 @@ struct Queue {
 
 }  // namespace
 
-extern "C" int lrc_rng_scan_draws(lrc_mt19937_state* st, uint64_t num_poses, uint64_t normals_per_pose,
-                                  uint64_t uniforms_per_pose, double loc, double scale, double* out_normals,
-                                  double* out_uniforms, int threads) {
-    if (!st) return lrc_internal_fail(LRC_ERR_INVALID_ARG, "lrc_rng_scan_draws: state is NULL");
-    if (st->pos < 0 || st->pos > kN) return lrc_internal_fail(LRC_ERR_INVALID_ARG, "lrc_rng_scan_draws: pos outside [0, 624]");
-    if ((normals_per_pose && num_poses && !out_normals) || (uniforms_per_pose && num_poses && !out_uniforms))
-        return lrc_internal_fail(LRC_ERR_INVALID_ARG, "lrc_rng_scan_draws: NULL output");
-    if (num_poses == 0 || (normals_per_pose == 0 && uniforms_per_pose == 0)) return LRC_OK;
+
+// ---- the streaming path ---------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr size_t kChunkWords = (size_t)1 << 18;          // 1 MiB of tempered words
+constexpr size_t kChunkGroups = kChunkWords / 4;         // aligned groups of four words = candidate attempts
+constexpr size_t kMaxAhead = 96;                         // chunks the generator may be ahead of the walk (memory bound)
+
+struct Chunk {
+    std::unique_ptr<uint32_t[]> w;                       // tempered words
+    std::unique_ptr<uint8_t[]> flag;                     // per group: it is an accepted attempt (if it is an attempt at all)
+    uint32_t count = 0;                                  // accepted groups of the chunk
+    uint32_t snap_key[kN];                               // the raw block that holds the chunk's first word ...
+    int snap_pos = 0;                                    // ... at this index
+    std::atomic<int> state{0};                           // 1 = words there, 2 = flags and count there
+    std::atomic<int> refs{1};                            // poses still to be transformed that read it (+1: the walk)
+};
+
+__attribute__((target_clones("avx2", "default")))
+uint32_t flag_groups(const uint32_t* __restrict__ w, size_t groups, uint8_t* __restrict__ flags) {
+    uint32_t acc = 0;
+    for (size_t k = 0; k < groups; ++k) {
+        const double x1 = 2.0 * to_double(w[4 * k], w[4 * k + 1]) - 1.0;
+        const double x2 = 2.0 * to_double(w[4 * k + 2], w[4 * k + 3]) - 1.0;
+        const double r2 = x1 * x1 + x2 * x2;
+        const uint32_t ok = (r2 >= 1.0 || r2 == 0.0) ? 0u : 1u;
+        flags[k] = (uint8_t)ok;
+        acc += ok;
+    }
+    return acc;
+}
+
+struct StreamJob {
+    uint64_t pose = 0;
+    uint64_t g0 = 0, attempts = 0;                       // first group, groups scanned (normals), then the uniforms' words
+};
+
+struct Streaming {
+    // fixed for the call
+    uint64_t P, nn, nu;
+    double loc, scale;
+    double* out_norm;
+    double* out_unif;
+    // chunks, created by the generator in order
+    std::mutex cm;                                       // guards `chunks` (the vector, not the chunks)
+    std::vector<std::unique_ptr<Chunk>> chunks;
+    std::atomic<size_t> generated{0};                    // chunks whose words are there
+    std::atomic<size_t> walk_chunk{0};                   // the chunk the walk is in (the generator stays < walk_chunk + kMaxAhead)
+    std::atomic<bool> stop{false};
+    std::atomic<bool> failed{false};                     // a thread ran out of memory: everybody winds down
+    // tasks
+    std::mutex qm;
+    std::condition_variable qcv;                         // tasks, and progress the walk waits for
+    std::deque<std::pair<int, uint64_t>> tasks;          // (0, chunk): flag it; (1, job index): transform it
+    std::vector<StreamJob> jobs;
+    bool closed = false;
+    std::atomic<uint64_t> poses_done{0};
+
+    Chunk* chunk(size_t c) {
+        std::lock_guard<std::mutex> l(cm);
+        return c < chunks.size() ? chunks[c].get() : nullptr;
+    }
+    void release(size_t c) {
+        Chunk* k = chunk(c);
+        if (k && k->refs.fetch_sub(1) == 1) { k->w.reset(); k->flag.reset(); }
+    }
+    void push(int kind, uint64_t v) {
+        { std::lock_guard<std::mutex> l(qm); tasks.emplace_back(kind, v); }
+        qcv.notify_all();
+    }
+    void run(std::pair<int, uint64_t> t) {
+        if (t.first == 0) {
+            Chunk* k = chunk((size_t)t.second);
+            k->flag.reset(new uint8_t[kChunkGroups]);
+            k->count = flag_groups(k->w.get(), kChunkGroups, k->flag.get());
+            k->state.store(2, std::memory_order_release);
+            { std::lock_guard<std::mutex> l(qm); }
+            qcv.notify_all();
+        } else {
+            transform(jobs[(size_t)t.second]);
+            poses_done.fetch_add(1);
+            { std::lock_guard<std::mutex> l(qm); }
+            qcv.notify_all();
+        }
+    }
+    // one task if there is one; false when the queue is empty
+    bool help() {
+        std::pair<int, uint64_t> t;
+        {
+            std::lock_guard<std::mutex> l(qm);
+            if (tasks.empty()) return false;
+            t = tasks.front();
+            tasks.pop_front();
+        }
+        run(t);
+        return true;
+    }
+    void worker() {
+        for (;;) {
+            std::pair<int, uint64_t> t;
+            {
+                std::unique_lock<std::mutex> l(qm);
+                qcv.wait(l, [&] { return closed || !tasks.empty(); });
+                if (tasks.empty()) return;
+                t = tasks.front();
+                tasks.pop_front();
+            }
+            try { run(t); } catch (...) { failed.store(true); stop.store(true); qcv.notify_all(); return; }
+        }
+    }
+    // the pose's normals (accepted groups in stream order: f * x2, then f * x1), then its uniforms
+    void transform(const StreamJob& j) {
+        double* on = out_norm ? out_norm + j.pose * nn : nullptr;
+        size_t o = 0;
+        uint64_t g = j.g0;
+        const uint64_t gend = j.g0 + j.attempts;
+        while (g < gend) {
+            const size_t c = (size_t)(g / kChunkGroups);
+            Chunk* k = chunk(c);
+            const size_t a = (size_t)(g % kChunkGroups), b = (size_t)std::min<uint64_t>(kChunkGroups, a + (gend - g));
+            const uint32_t* w = k->w.get();
+            const uint8_t* f = k->flag.get();
+            for (size_t q = a; q < b; ++q) {
+                if (!f[q]) continue;
+                const double x1 = 2.0 * to_double(w[4 * q], w[4 * q + 1]) - 1.0;
+                const double x2 = 2.0 * to_double(w[4 * q + 2], w[4 * q + 3]) - 1.0;
+                const double r2 = x1 * x1 + x2 * x2;
+                const double fac = std::sqrt(-2.0 * std::log(r2) / r2);
+                on[o++] = loc + scale * (fac * x2);
+                on[o++] = loc + scale * (fac * x1);
+            }
+            g += b - a;
+        }
+        double* ou = out_unif ? out_unif + j.pose * nu : nullptr;
+        uint64_t wpos = 4 * gend;                         // word offset of the first uniform
+        size_t left = (size_t)nu, u = 0;
+        while (left) {
+            const size_t c = (size_t)(wpos / kChunkWords);
+            Chunk* k = chunk(c);
+            const size_t a = (size_t)(wpos % kChunkWords);
+            const size_t m = std::min(left, (kChunkWords - a) / 2);
+            const uint32_t* w = k->w.get() + a;
+            for (size_t q = 0; q < m; ++q) ou[u + q] = to_double(w[2 * q], w[2 * q + 1]);
+            u += m; left -= m; wpos += 2 * m;
+        }
+        // this pose no longer needs its chunks
+        const size_t c0 = (size_t)(j.g0 / kChunkGroups);
+        const uint64_t last_word = 4 * gend + 2 * nu;     // one past
+        const size_t c1 = last_word ? (size_t)((last_word - 1) / kChunkWords) : c0;
+        for (size_t c = c0; c <= c1; ++c) release(c);
+    }
+};
+
+// tempered words into chunk after chunk until told to stop (the only sequential part of the whole draw)
+void generate(Streaming* S, const uint32_t* key0, int pos0) try {
+    uint32_t a[kN], b[kN];
+    uint32_t* cur = a;
+    uint32_t* nxt = b;
+    std::memcpy(cur, key0, sizeof(a));
+    int rp = pos0;
+    for (size_t c = 0; !S->stop.load(std::memory_order_acquire); ++c) {
+        while (c >= S->walk_chunk.load(std::memory_order_acquire) + kMaxAhead && !S->stop.load(std::memory_order_acquire))
+            std::this_thread::sleep_for(std::chrono::microseconds(50));      // far ahead of the walk: rare, and no hurry
+        if (S->stop.load(std::memory_order_acquire)) break;
+        auto k = std::make_unique<Chunk>();
+        k->w.reset(new uint32_t[kChunkWords]);
+        if (rp == kN) { mt_next_block(cur, nxt); std::swap(cur, nxt); rp = 0; }
+        std::memcpy(k->snap_key, cur, sizeof(k->snap_key));
+        k->snap_pos = rp;
+        size_t filled = 0;
+        while (filled < kChunkWords) {
+            if (rp == kN) { mt_next_block(cur, nxt); std::swap(cur, nxt); rp = 0; }
+            const size_t m = std::min(kChunkWords - filled, (size_t)(kN - rp));
+            temper_block(cur + rp, k->w.get() + filled, m);
+            filled += m;
+            rp += (int)m;
+        }
+        k->state.store(1, std::memory_order_release);
+        { std::lock_guard<std::mutex> l(S->cm); S->chunks.push_back(std::move(k)); }
+        S->generated.store(c + 1, std::memory_order_release);
+        S->push(0, c);
+    }
+} catch (...) {
+    S->failed.store(true);
+    S->stop.store(true);
+    S->qcv.notify_all();
+}
+
+int scan_streaming(lrc_mt19937_state* st, uint64_t num_poses, uint64_t normals_per_pose, uint64_t uniforms_per_pose,
+                   double loc, double scale, double* out_normals, double* out_uniforms, int nthreads) {
+    Streaming S;
+    S.P = num_poses; S.nn = normals_per_pose; S.nu = uniforms_per_pose;
+    S.loc = loc; S.scale = scale; S.out_norm = out_normals; S.out_unif = out_uniforms;
+    S.jobs.resize((size_t)num_poses);
+    std::thread gen(generate, &S, (const uint32_t*)st->key, st->pos);
+    std::vector<std::thread> pool;
+    for (int t = 2; t < nthreads; ++t) pool.emplace_back([&S] { S.worker(); });
+    // the walk: wait for chunk c's flags (helping with tasks meanwhile)
+    auto flagged = [&](size_t c) -> Chunk* {
+        for (;;) {
+            if (S.failed.load()) throw std::bad_alloc();
+            if (c < S.generated.load(std::memory_order_acquire)) {
+                Chunk* k = S.chunk(c);
+                if (k->state.load(std::memory_order_acquire) == 2) return k;
+            }
+            if (!S.help()) {
+                std::unique_lock<std::mutex> l(S.qm);
+                S.qcv.wait_for(l, std::chrono::microseconds(200));
+            }
+        }
+    };
+    uint64_t G = 0;                                      // group cursor
+    bool bad = false;
+    try {
+    size_t held = 0;                                     // chunks below this have been released by the walk
+    const uint64_t need_per_pose = normals_per_pose / 2, ugroups = uniforms_per_pose / 2;
+    for (uint64_t p = 0; p < num_poses; ++p) {
+        StreamJob& j = S.jobs[(size_t)p];
+        j.pose = p; j.g0 = G;
+        uint64_t need = need_per_pose, g = G;
+        while (need) {
+            const size_t c = (size_t)(g / kChunkGroups), a = (size_t)(g % kChunkGroups);
+            S.walk_chunk.store(std::max(S.walk_chunk.load(std::memory_order_relaxed), c), std::memory_order_release);
+            Chunk* k = flagged(c);
+            if (a == 0 && k->count < need) { need -= k->count; g += kChunkGroups; continue; }
+            const uint8_t* f = k->flag.get();
+            size_t q = a;
+            for (; q < kChunkGroups && need; ++q) need -= f[q];
+            g += q - a;
+        }
+        j.attempts = g - G;
+        G = g + ugroups;
+        // the pose's chunks stay until its transform is done; the walk lets go of the chunks it has left behind
+        const uint64_t last_word = 4 * g + 2 * uniforms_per_pose;
+        const size_t c0 = (size_t)(j.g0 / kChunkGroups), c1 = last_word ? (size_t)((last_word - 1) / kChunkWords) : c0;
+        for (size_t c = c0; c <= c1; ++c) {
+            S.walk_chunk.store(std::max(S.walk_chunk.load(std::memory_order_relaxed), c), std::memory_order_release);
+            Chunk* k = flagged(c);
+            k->refs.fetch_add(1);
+        }
+        S.push(1, p);
+        const size_t now = (size_t)(G / kChunkGroups);
+        S.walk_chunk.store(std::max(S.walk_chunk.load(std::memory_order_relaxed), now), std::memory_order_release);
+        for (; held < now; ++held) S.release(held);
+    }
+    S.stop.store(true, std::memory_order_release);
+    while (S.poses_done.load() < num_poses) {
+        if (S.failed.load()) throw std::bad_alloc();
+        if (!S.help()) {
+            std::unique_lock<std::mutex> l(S.qm);
+            S.qcv.wait_for(l, std::chrono::microseconds(200));
+        }
+    }
+    } catch (...) { bad = true; }
+    S.stop.store(true, std::memory_order_release);
+    { std::lock_guard<std::mutex> l(S.qm); S.closed = true; S.tasks.clear(); }
+    S.qcv.notify_all();
+    gen.join();
+    for (auto& t : pool) t.join();
+    if (bad || S.failed.load()) throw std::bad_alloc();
+    // the generator state numpy would be left with: key = the raw block of the last word consumed, pos = one past it
+    const uint64_t W = 4 * G;
+    if (W) {
+        const size_t c = (size_t)((W - 1) / kChunkWords);
+        Chunk* k = S.chunk(c);
+        const uint64_t idx = (uint64_t)k->snap_pos + ((W - 1) - (uint64_t)c * kChunkWords);
+        uint32_t a[kN], b[kN];
+        uint32_t* cur = a;
+        uint32_t* nxt = b;
+        std::memcpy(cur, k->snap_key, sizeof(a));
+        for (uint64_t s = 0; s < idx / kN; ++s) { mt_next_block(cur, nxt); std::swap(cur, nxt); }
+        std::memcpy(st->key, cur, sizeof(a));
+        st->pos = (int)(idx % kN) + 1;
+    }
+    st->has_gauss = 0;
+    st->gauss = 0.0;
+    return LRC_OK;
+}
+
+}  // namespace
+
+static int scan_sequential(lrc_mt19937_state* st, uint64_t num_poses, uint64_t normals_per_pose,
+                           uint64_t uniforms_per_pose, double loc, double scale, double* out_normals,
+                           double* out_uniforms, int threads) {
     try {
         Stream s;
         s.init(st->key, st->pos);
@@ -294,4 +577,29 @@ extern "C" int lrc_rng_scan_draws(lrc_mt19937_state* st, uint64_t num_poses, uin
         return lrc_internal_fail(LRC_ERR_INTERNAL, "lrc_rng_scan_draws: failed");
     }
     return LRC_OK;
+}
+
+extern "C" int lrc_rng_scan_draws(lrc_mt19937_state* st, uint64_t num_poses, uint64_t normals_per_pose,
+                                  uint64_t uniforms_per_pose, double loc, double scale, double* out_normals,
+                                  double* out_uniforms, int threads) {
+    if (!st) return lrc_internal_fail(LRC_ERR_INVALID_ARG, "lrc_rng_scan_draws: state is NULL");
+    if (st->pos < 0 || st->pos > kN) return lrc_internal_fail(LRC_ERR_INVALID_ARG, "lrc_rng_scan_draws: pos outside [0, 624]");
+    if ((normals_per_pose && num_poses && !out_normals) || (uniforms_per_pose && num_poses && !out_uniforms))
+        return lrc_internal_fail(LRC_ERR_INVALID_ARG, "lrc_rng_scan_draws: NULL output");
+    if (num_poses == 0 || (normals_per_pose == 0 && uniforms_per_pose == 0)) return LRC_OK;
+    const unsigned hw = std::thread::hardware_concurrency();
+    int nthreads = threads > 0 ? threads : (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+    // threads < 0: the sequential path with |threads| threads (tests compare the two paths)
+    const bool aligned = normals_per_pose % 2 == 0 && uniforms_per_pose % 2 == 0 && !st->has_gauss;
+    if (threads >= 0 && aligned && nthreads >= 3 && num_poses * (normals_per_pose + uniforms_per_pose) >= (1u << 16)) {
+        try {
+            return scan_streaming(st, num_poses, normals_per_pose, uniforms_per_pose, loc, scale, out_normals, out_uniforms, nthreads);
+        } catch (const std::bad_alloc&) {
+            return lrc_internal_fail(LRC_ERR_OOM, "lrc_rng_scan_draws: out of host memory");
+        } catch (...) {
+            return lrc_internal_fail(LRC_ERR_INTERNAL, "lrc_rng_scan_draws: failed");
+        }
+    }
+    return scan_sequential(st, num_poses, normals_per_pose, uniforms_per_pose, loc, scale, out_normals, out_uniforms,
+                           threads < 0 ? -threads : threads);
 }

@@ -47,6 +47,41 @@ def test_matches_numpy(seed, P, nn, nu, pre, threads):
     assert np.array_equal(ref.normal(size=5), mine.normal(size=5)) and ref.randint(1 << 30) == mine.randint(1 << 30)
 
 
+@pytest.mark.parametrize("seed,P,nn,nu,pre_words", [
+    (0, 7, 20000, 10000, 0),          # even counts, no cached normal, enough work: the streaming path
+    (2, 40, 2000, 1000, 1),           # the stream starts one word into a block
+    (4, 5, 30000, 14000, 623),        # ... on the last word of a block
+    (4, 5, 30000, 14000, 624),        # ... on a block end (numpy regenerates lazily: pos stays 624)
+    (6, 3, 600000, 300000, 311),      # poses that span eight 1 MiB chunks: whole chunks skipped by their counts
+    (8, 9, 0, 40000, 5),              # uniforms only
+    (9, 9, 40000, 0, 7),              # normals only
+])
+@pytest.mark.parametrize("threads", [3, 8])
+def test_streaming_path_matches_numpy_and_the_sequential_path(seed, P, nn, nu, pre_words, threads):
+    """Even counts and no cached normal: one thread generates words and does nothing else, workers flag every aligned group
+    of four words as an accepted polar attempt or not, the caller walks the counts (lrc_nprandom.cpp: scan_streaming).
+    The doubles, their order and the generator state afterwards are numpy's; threads < 0 selects the sequential path."""
+    from lidarcast import nprandom
+    ref, mine, seq = (np.random.RandomState(seed) for _ in range(3))
+    for rs in (ref, mine, seq):
+        if pre_words:
+            rs.randint(0, 1 << 32, size=pre_words, dtype=np.uint32)       # one word each
+    assert ref.get_state()[2] == (pre_words % 624 if pre_words else 624) or pre_words == 624
+    zr, ur = _numpy_draws(ref, P, nn, nu, -0.5, 2e-3)
+    zm, um = nprandom.scan_draws(P, nn, nu, -0.5, 2e-3, rng=mine, threads=threads)
+    zs, us = nprandom.scan_draws(P, nn, nu, -0.5, 2e-3, rng=seq, threads=-threads)
+    for z, u, rs in ((zm, um, mine), (zs, us, seq)):
+        assert np.array_equal(zr.view(np.uint64), z.view(np.uint64))
+        assert np.array_equal(ur.view(np.uint64), u.view(np.uint64))
+        assert _same_state(ref.get_state(), rs.get_state())
+    # a second call continues the stream (now from a mid-block position), then numpy itself does
+    zr2, ur2 = _numpy_draws(ref, 2, nn, nu, 0.0, 1.0)
+    zm2, um2 = nprandom.scan_draws(2, nn, nu, 0.0, 1.0, rng=mine, threads=threads)
+    assert np.array_equal(zr2.view(np.uint64), zm2.view(np.uint64)) and np.array_equal(ur2.view(np.uint64), um2.view(np.uint64))
+    assert _same_state(ref.get_state(), mine.get_state())
+    assert np.array_equal(ref.normal(size=3), mine.normal(size=3))
+
+
 def test_global_stream_and_sensor_sized_draw():
     """np.random itself (what the reference uses), one BLK2GO pose: 128 000 normals of sigma 1e-3, 64 000 uniforms."""
     from lidarcast import nprandom

@@ -260,9 +260,26 @@ struct Streaming {
         std::lock_guard<std::mutex> l(cm);
         return c < chunks.size() ? chunks[c].get() : nullptr;
     }
+    // buffers of chunks nobody reads any more go back to the generator / the flag tasks (fresh memory costs page faults:
+    // a third of the generator's time)
+    std::mutex fm;
+    std::vector<std::unique_ptr<uint32_t[]>> free_words;
+    std::vector<std::unique_ptr<uint8_t[]>> free_flags;
+    std::unique_ptr<uint32_t[]> take_words() {
+        { std::lock_guard<std::mutex> l(fm); if (!free_words.empty()) { auto b = std::move(free_words.back()); free_words.pop_back(); return b; } }
+        return std::unique_ptr<uint32_t[]>(new uint32_t[kChunkWords]);
+    }
+    std::unique_ptr<uint8_t[]> take_flags() {
+        { std::lock_guard<std::mutex> l(fm); if (!free_flags.empty()) { auto b = std::move(free_flags.back()); free_flags.pop_back(); return b; } }
+        return std::unique_ptr<uint8_t[]>(new uint8_t[kChunkGroups]);
+    }
     void release(size_t c) {
         Chunk* k = chunk(c);
-        if (k && k->refs.fetch_sub(1) == 1) { k->w.reset(); k->flag.reset(); }
+        if (k && k->refs.fetch_sub(1) == 1) {
+            std::lock_guard<std::mutex> l(fm);
+            if (k->w) free_words.push_back(std::move(k->w));
+            if (k->flag) free_flags.push_back(std::move(k->flag));
+        }
     }
     void push(int kind, uint64_t v) {
         { std::lock_guard<std::mutex> l(qm); tasks.emplace_back(kind, v); }
@@ -271,7 +288,7 @@ struct Streaming {
     void run(std::pair<int, uint64_t> t) {
         if (t.first == 0) {
             Chunk* k = chunk((size_t)t.second);
-            k->flag.reset(new uint8_t[kChunkGroups]);
+            k->flag = take_flags();
             k->count = flag_groups(k->w.get(), kChunkGroups, k->flag.get());
             k->state.store(2, std::memory_order_release);
             { std::lock_guard<std::mutex> l(qm); }
@@ -363,7 +380,7 @@ void generate(Streaming* S, const uint32_t* key0, int pos0) try {
             std::this_thread::sleep_for(std::chrono::microseconds(50));      // far ahead of the walk: rare, and no hurry
         if (S->stop.load(std::memory_order_acquire)) break;
         auto k = std::make_unique<Chunk>();
-        k->w.reset(new uint32_t[kChunkWords]);
+        k->w = S->take_words();
         if (rp == kN) { mt_next_block(cur, nxt); std::swap(cur, nxt); rp = 0; }
         std::memcpy(k->snap_key, cur, sizeof(k->snap_key));
         k->snap_pos = rp;

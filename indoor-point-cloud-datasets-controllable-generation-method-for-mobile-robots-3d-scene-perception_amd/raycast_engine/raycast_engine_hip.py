@@ -58,6 +58,12 @@ def _fingerprint(v, f, full=False):
 _RAY_POOL = None
 
 
+# threads of the native draws of the seeded stream: one generates words, the others flag and transform; the pool below
+# (numpy trigonometry, pose by pose) needs cores beside them
+import os as _os
+_DRAW_THREADS = int(_os.environ.get("LRC_DRAW_THREADS", "4"))
+
+
 def _ray_pool():
     """Threads for the host-side ray generation of the dual-axis sensor (pure numpy work per pose)."""
     global _RAY_POOL
@@ -97,7 +103,7 @@ def dual_axis_rays_batch(lidars, rays, keep):
         run = 16
         for a in range(0, P, run):
             b = min(P, a + run)
-            z, u = nprandom.scan_draws(b - a, nn, nu, 0.0, k0.angle_noise_std, rng=rng)
+            z, u = nprandom.scan_draws(b - a, nn, nu, 0.0, k0.angle_noise_std, rng=rng, threads=_DRAW_THREADS)
             for i in range(a, b):
                 pending.append(pool.submit(one, lidars[i], z[i - a] if nn else None, u[i - a] if nu else None,
                                            rays[i], keep[i]))

@@ -29,6 +29,14 @@ for th in (1, 2, 4, 8, 16):
     dt = time.perf_counter() - t0
     print(f"native, {th:2d} threads, runs of 16 poses: {dt / P * 1e3:.3f} ms per pose -> {dt:.3f} s for {P} poses")
 
+for run in (16, 32, 64, 128, 256):
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    for a in range(0, P, run):
+        nprandom.scan_draws(min(run, P - a), 128000, 64000, 0.0, 1e-3)
+    dt = time.perf_counter() - t0
+    print(f"native, default threads, runs of {run:3d} poses: {dt / P * 1e3:.3f} ms per pose -> {dt:.3f} s for {P} poses")
+
 from lidar import DualAxisLidarIntrinsics, create_lidar  # noqa: E402
 from raycast_engine.raycast_engine_hip import dual_axis_rays_batch  # noqa: E402
 from trajectory import line_trajectory, poses_from_waypoints  # noqa: E402

@@ -346,6 +346,14 @@ int lrc_rng_scan_draws(lrc_mt19937_state* state, uint64_t num_poses, uint64_t no
                        uint64_t uniforms_per_pose, double loc, double scale, double* out_normals,
                        double* out_uniforms, int threads);
 
+/* The rays of one dual-axis pose from the sines and cosines of its scan angles (numpy's own, which only numpy reproduces):
+ * d = (cos(theta) cos(phi), cos(theta) sin(phi), sin(theta)) rotated as the reference rotates it, ray by ray and un-fused,
+ * (d0 R[j][0] + d1 R[j][1]) + d2 R[j][2], narrowed to float32 beside the pose's origin (lidar/indoor_lidar.py:274-291).
+ * pose16: row-major 4x4 float64; out_rays6: (n, 6) float32.  Host code: the dozen numpy passes this replaces were what
+ * bounded the BLK2GO trajectory once the draws were native. */
+int lrc_rays_from_trig(const double* cos_theta, const double* sin_theta, const double* cos_phi, const double* sin_phi,
+                       uint64_t n, const double* pose16, float* out_rays6);
+
 /* ---- diagnostics ---------------------------------------------------------------------------------------
  * Per-ray traversal counters of a pose-batched scan from an instrumented build of the trace kernel, host arrays.
  * stats: (num_poses * rays_per_pose, LRC_STATS_WORDS) uint32: [0] inner-node steps, [1] triangle tests, [2] node steps

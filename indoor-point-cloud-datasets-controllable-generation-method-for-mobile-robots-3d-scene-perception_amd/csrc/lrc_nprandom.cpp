@@ -620,3 +620,28 @@ extern "C" int lrc_rng_scan_draws(lrc_mt19937_state* st, uint64_t num_poses, uin
     return scan_sequential(st, num_poses, normals_per_pose, uniforms_per_pose, loc, scale, out_normals, out_uniforms,
                            threads < 0 ? -threads : threads);
 }
+
+// ---- the rays of a dual-axis pose from numpy's sines and cosines (include/lidarcast.h) --------------------------------------
+__attribute__((target_clones("avx2", "default")))
+static void rays_from_trig(const double* __restrict__ ct, const double* __restrict__ st, const double* __restrict__ cp,
+                           const double* __restrict__ sp, uint64_t n, const double* __restrict__ M, float* __restrict__ out) {
+    const float ox = (float)M[3], oy = (float)M[7], oz = (float)M[11];
+    const double r00 = M[0], r01 = M[1], r02 = M[2], r10 = M[4], r11 = M[5], r12 = M[6], r20 = M[8], r21 = M[9], r22 = M[10];
+    for (uint64_t i = 0; i < n; ++i) {
+        const double d0 = ct[i] * cp[i], d1 = ct[i] * sp[i], d2 = st[i];
+        float* o = out + 6 * i;
+        o[0] = ox; o[1] = oy; o[2] = oz;
+        o[3] = (float)((d0 * r00 + d1 * r01) + d2 * r02);
+        o[4] = (float)((d0 * r10 + d1 * r11) + d2 * r12);
+        o[5] = (float)((d0 * r20 + d1 * r21) + d2 * r22);
+    }
+}
+
+extern "C" int lrc_rays_from_trig(const double* cos_theta, const double* sin_theta, const double* cos_phi, const double* sin_phi,
+                                  uint64_t n, const double* pose16, float* out_rays6) {
+    if (n && (!cos_theta || !sin_theta || !cos_phi || !sin_phi || !pose16 || !out_rays6))
+        return lrc_internal_fail(LRC_ERR_INVALID_ARG, "lrc_rays_from_trig: NULL argument");
+    if (n == 0) return LRC_OK;
+    rays_from_trig(cos_theta, sin_theta, cos_phi, sin_phi, n, pose16, out_rays6);
+    return LRC_OK;
+}

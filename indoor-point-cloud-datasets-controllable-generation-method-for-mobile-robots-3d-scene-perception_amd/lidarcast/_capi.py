@@ -35,7 +35,7 @@ SYMBOLS = (
     "lrc_nn_create", "lrc_nn_destroy", "lrc_nn_query", "lrc_nn_query_dev",
     "lrc_min_distances", "lrc_rbf_kernel_sum",
     "lrc_occ_create", "lrc_occ_destroy", "lrc_occ_query",
-    "lrc_rng_scan_draws",
+    "lrc_rng_scan_draws", "lrc_rays_from_trig",
 )
 
 
@@ -155,6 +155,7 @@ def load():
         "lrc_compact": [vp, u64, u64, C.POINTER(LrcCompactIO), C.POINTER(u64)],
         "lrc_compact_dev": [vp, u64, u64, C.POINTER(LrcCompactIO), vp],
         "lrc_rng_scan_draws": [C.POINTER(LrcMt19937State), u64, u64, u64, dbl, dbl, vp, vp, i32],
+        "lrc_rays_from_trig": [vp, vp, vp, vp, u64, vp, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)

@@ -95,11 +95,31 @@ def dual_axis_rays_batch(lidars, rays, keep):
         nn = 2 * n if k0.angle_noise_std > 0 else 0
         nu = n if k0.dropout_probability > 0 else 0
 
+        from lidarcast import _capi
+        lib = _capi.load()
+        p_drop = k0.dropout_probability
+        native_out = rays.dtype == np.float32 and rays[0].flags.c_contiguous
+
         def one(l, z, u, out, km):
-            phi, theta, k = l.scan_angles_from_draws(z, u)
-            if k is not None:
-                km[:] = k
-            l.rays_from_angles(phi, theta, out)
+            # the angles and the dropout as scan_angles_from_draws forms them; the sines and cosines are numpy's own
+            # (nothing else reproduces them bit for bit); products, rotation and narrowing in one native pass
+            # (lrc_rays_from_trig: the reference's arithmetic, un-fused) instead of a dozen numpy passes over temporaries
+            if not native_out:
+                phi, theta, k = l.scan_angles_from_draws(z, u)
+                if k is not None:
+                    km[:] = k
+                l.rays_from_angles(phi, theta, out)
+                return
+            phi, theta = l.scan_pattern(None)
+            if z is not None:
+                zz = z.reshape(phi.size, 2)
+                phi, theta = phi + zz[:, 0], theta + zz[:, 1]
+            if u is not None:
+                km[:] = u > p_drop
+            ct, st, cp, sp = np.cos(theta), np.sin(theta), np.cos(phi), np.sin(phi)
+            M = np.ascontiguousarray(l.pose, dtype=np.float64)
+            _capi.check(lib.lrc_rays_from_trig(ct.ctypes.data, st.ctypes.data, cp.ctypes.data, sp.ctypes.data, phi.size,
+                                               M.ctypes.data, out.ctypes.data), "lrc_rays_from_trig")
         run = 16
         for a in range(0, P, run):
             b = min(P, a + run)

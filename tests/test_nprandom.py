@@ -139,3 +139,36 @@ def test_trajectory_rays_match_per_pose_generator(seed):
         for i in range(len(poses)):
             got = rays[i][keep[i].astype(bool)]
             assert got.shape == ref[i].shape and np.array_equal(got.view(np.uint32), ref[i].view(np.uint32)), i
+
+
+def test_native_ray_composition_equals_the_numpy_formula():
+    """lrc_rays_from_trig (products, rotation, narrowing of a dual-axis pose in one native pass) against
+    IndoorLidar.rays_from_angles, the numpy form of the reference's arithmetic (lidar/indoor_lidar.py:274-291): the same
+    float32 bits for a pose rotated about all three axes, angles over the whole range, non-finite values passed through."""
+    import ctypes as C
+    from lidarcast import _capi
+    from lidar import DualAxisLidarIntrinsics, create_lidar
+    lib = _capi.load()
+    rng = np.random.default_rng(11)
+    n = 10007
+    phi = rng.uniform(-7.0, 7.0, n)
+    theta = rng.uniform(-1.6, 1.6, n)
+    phi[:3] = [0.0, np.pi, -0.0]
+    theta[3:6] = [np.pi / 2, -np.pi / 2, 0.0]
+    a, b, c = 0.7, -0.31, 1.9
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(c), -np.sin(c)], [0, np.sin(c), np.cos(c)]])
+    pose = np.eye(4)
+    pose[:3, :3] = Rz @ Ry @ Rx
+    pose[:3, 3] = [1.2345678901, -7.000000123, 0.333333333333]
+    lidar = create_lidar(DualAxisLidarIntrinsics.create_blk2go_dual_axis(), pose)
+    ref = lidar.rays_from_angles(phi, theta)
+    out = np.full((n, 6), np.nan, dtype=np.float32)
+    ct, st, cp, sp = np.cos(theta), np.sin(theta), np.cos(phi), np.sin(phi)
+    M = np.ascontiguousarray(pose, dtype=np.float64)
+    _capi.check(lib.lrc_rays_from_trig(ct.ctypes.data, st.ctypes.data, cp.ctypes.data, sp.ctypes.data, n, M.ctypes.data,
+                                       out.ctypes.data), "lrc_rays_from_trig")
+    assert np.array_equal(ref.view(np.uint32), out.view(np.uint32))
+    assert lib.lrc_rays_from_trig(None, None, None, None, 0, None, None) == 0
+    assert lib.lrc_rays_from_trig(None, st.ctypes.data, cp.ctypes.data, sp.ctypes.data, n, M.ctypes.data, out.ctypes.data) != 0

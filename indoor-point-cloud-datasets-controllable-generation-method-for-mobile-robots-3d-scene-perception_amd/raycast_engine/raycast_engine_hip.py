@@ -74,6 +74,30 @@ def _ray_pool():
     return _RAY_POOL
 
 
+def _pose_rays_numpy(l, z, u, out, km):
+    phi, theta, k = l.scan_angles_from_draws(z, u)
+    if k is not None:
+        km[:] = k
+    l.rays_from_angles(phi, theta, out)
+
+
+def _pose_rays_native(l, z, u, out, km):
+    """One pose's rays and dropout mask from its draws: the angles and the mask as scan_angles_from_draws forms them, the
+    sines and cosines by numpy (nothing else reproduces them bit for bit), then products, rotation and narrowing in ONE
+    native pass (lrc_rays_from_trig: the reference's un-fused arithmetic) instead of a dozen numpy passes over temporaries."""
+    from lidarcast import _capi
+    phi, theta = l.scan_pattern(None)
+    if z is not None:
+        zz = z.reshape(phi.size, 2)
+        phi, theta = phi + zz[:, 0], theta + zz[:, 1]
+    if u is not None:
+        km[:] = u > l.intrinsics.dropout_probability
+    ct, st, cp, sp = np.cos(theta), np.sin(theta), np.cos(phi), np.sin(phi)
+    M = np.ascontiguousarray(l.pose, dtype=np.float64)
+    _capi.check(_capi.load().lrc_rays_from_trig(ct.ctypes.data, st.ctypes.data, cp.ctypes.data, sp.ctypes.data, phi.size,
+                                                M.ctypes.data, out.ctypes.data), "lrc_rays_from_trig")
+
+
 def dual_axis_rays_batch(lidars, rays, keep):
     """All rays of all poses of a dual-axis trajectory BEFORE the dropout, into ``rays`` (P, n, 6) float32, and the dropout
     masks into ``keep`` (P, n) uint8/bool (pre-set to 1) -- ``rays[i][keep[i]]`` is ``lidars[i].get_rays()`` and the
@@ -95,31 +119,8 @@ def dual_axis_rays_batch(lidars, rays, keep):
         nn = 2 * n if k0.angle_noise_std > 0 else 0
         nu = n if k0.dropout_probability > 0 else 0
 
-        from lidarcast import _capi
-        lib = _capi.load()
-        p_drop = k0.dropout_probability
         native_out = rays.dtype == np.float32 and rays[0].flags.c_contiguous
-
-        def one(l, z, u, out, km):
-            # the angles and the dropout as scan_angles_from_draws forms them; the sines and cosines are numpy's own
-            # (nothing else reproduces them bit for bit); products, rotation and narrowing in one native pass
-            # (lrc_rays_from_trig: the reference's arithmetic, un-fused) instead of a dozen numpy passes over temporaries
-            if not native_out:
-                phi, theta, k = l.scan_angles_from_draws(z, u)
-                if k is not None:
-                    km[:] = k
-                l.rays_from_angles(phi, theta, out)
-                return
-            phi, theta = l.scan_pattern(None)
-            if z is not None:
-                zz = z.reshape(phi.size, 2)
-                phi, theta = phi + zz[:, 0], theta + zz[:, 1]
-            if u is not None:
-                km[:] = u > p_drop
-            ct, st, cp, sp = np.cos(theta), np.sin(theta), np.cos(phi), np.sin(phi)
-            M = np.ascontiguousarray(l.pose, dtype=np.float64)
-            _capi.check(lib.lrc_rays_from_trig(ct.ctypes.data, st.ctypes.data, cp.ctypes.data, sp.ctypes.data, phi.size,
-                                               M.ctypes.data, out.ctypes.data), "lrc_rays_from_trig")
+        one = _pose_rays_native if native_out else _pose_rays_numpy
         run = 16
         for a in range(0, P, run):
             b = min(P, a + run)

@@ -26,12 +26,18 @@ np.random.seed(0)
 z, u = nprandom.scan_draws(16, 2 * n, n, 0.0, kd.angle_noise_std)
 
 
-def one(l, zz, uu, out, km):
-    phi, theta, k = l.scan_angles_from_draws(zz, uu)
-    if k is not None:
-        km[:] = k
-    l.rays_from_angles(phi, theta, out)
+from raycast_engine.raycast_engine_hip import _pose_rays_native as one, _pose_rays_numpy  # noqa: E402
 
+t0 = time.perf_counter()
+for i in range(16):
+    _pose_rays_numpy(lidars[i], z[i], u[i], rays[i], keep[i])
+print(f"angles + rays of one pose, numpy only, one thread: {(time.perf_counter() - t0) / 16 * 1e3:.3f} ms")
+th = np.random.default_rng(0).uniform(-1, 1, n)
+for name, f in (("cos", np.cos), ("sin", np.sin)):
+    t0 = time.perf_counter()
+    for _ in range(50):
+        f(th)
+    print(f"np.{name} of {n} float64: {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms")
 
 for rep in range(3):
     t0 = time.perf_counter()

@@ -207,21 +207,40 @@ constexpr size_t kChunkGroups = kChunkWords / 4;         // aligned groups of fo
 constexpr size_t kMaxAhead = 96;                         // chunks the generator may be ahead of the walk (memory bound)
 
 struct Chunk {
-    std::unique_ptr<uint32_t[]> w;                       // tempered words
+    std::unique_ptr<uint32_t[]> buf;                     // kN words of history (raw), then the chunk's kChunkWords words:
+                                                         // raw as generated, tempered in place by the flag task
+    uint32_t* w = nullptr;                               // buf + kN
     std::unique_ptr<uint8_t[]> flag;                     // per group: it is an accepted attempt (if it is an attempt at all)
     uint32_t count = 0;                                  // accepted groups of the chunk
-    uint32_t snap_key[kN];                               // the raw block that holds the chunk's first word ...
-    int snap_pos = 0;                                    // ... at this index
-    std::atomic<int> state{0};                           // 1 = words there, 2 = flags and count there
+    uint32_t history[kN];                                // the kN raw words before the chunk (chunk 0: the caller's key)
+    std::atomic<int> state{0};                           // 1 = raw words there, 2 = tempered, flags and count there
     std::atomic<int> refs{1};                            // poses still to be transformed that read it (+1: the walk)
 };
 
+// MT19937 as a stream: word j from the words 624, 623 and 227 places before it (the block form's mt[i], mt[i + 1],
+// mt[i + 397] seen from one contiguous array).  No dependence shorter than 227: runs of 224 vectorise.
 __attribute__((target_clones("avx2", "default")))
-uint32_t flag_groups(const uint32_t* __restrict__ w, size_t groups, uint8_t* __restrict__ flags) {
+void mt_stream(uint32_t* __restrict__ b, size_t j0, size_t j1) {
+    for (size_t j = j0; j < j1;) {
+        const size_t m = std::min<size_t>(224, j1 - j);
+#pragma GCC ivdep
+        for (size_t q = j; q < j + m; ++q) {
+            const uint32_t y = (b[q - kN] & kUpper) | (b[q - kN + 1] & kLower);
+            b[q] = b[q - (kN - kM)] ^ (y >> 1) ^ ((0u - (y & 1u)) & kMatrixA);
+        }
+        j += m;
+    }
+}
+
+// tempering in place and the acceptance flags of a chunk in one pass (worker threads)
+__attribute__((target_clones("avx2", "default")))
+uint32_t temper_and_flag(uint32_t* __restrict__ w, size_t groups, uint8_t* __restrict__ flags) {
     uint32_t acc = 0;
     for (size_t k = 0; k < groups; ++k) {
-        const double x1 = 2.0 * to_double(w[4 * k], w[4 * k + 1]) - 1.0;
-        const double x2 = 2.0 * to_double(w[4 * k + 2], w[4 * k + 3]) - 1.0;
+        const uint32_t a = temper(w[4 * k]), b = temper(w[4 * k + 1]), c = temper(w[4 * k + 2]), d = temper(w[4 * k + 3]);
+        w[4 * k] = a; w[4 * k + 1] = b; w[4 * k + 2] = c; w[4 * k + 3] = d;
+        const double x1 = 2.0 * to_double(a, b) - 1.0;
+        const double x2 = 2.0 * to_double(c, d) - 1.0;
         const double r2 = x1 * x1 + x2 * x2;
         const uint32_t ok = (r2 >= 1.0 || r2 == 0.0) ? 0u : 1u;
         flags[k] = (uint8_t)ok;
@@ -267,7 +286,7 @@ struct Streaming {
     std::vector<std::unique_ptr<uint8_t[]>> free_flags;
     std::unique_ptr<uint32_t[]> take_words() {
         { std::lock_guard<std::mutex> l(fm); if (!free_words.empty()) { auto b = std::move(free_words.back()); free_words.pop_back(); return b; } }
-        return std::unique_ptr<uint32_t[]>(new uint32_t[kChunkWords]);
+        return std::unique_ptr<uint32_t[]>(new uint32_t[kN + kChunkWords]);
     }
     std::unique_ptr<uint8_t[]> take_flags() {
         { std::lock_guard<std::mutex> l(fm); if (!free_flags.empty()) { auto b = std::move(free_flags.back()); free_flags.pop_back(); return b; } }
@@ -277,8 +296,9 @@ struct Streaming {
         Chunk* k = chunk(c);
         if (k && k->refs.fetch_sub(1) == 1) {
             std::lock_guard<std::mutex> l(fm);
-            if (k->w) free_words.push_back(std::move(k->w));
+            if (k->buf) free_words.push_back(std::move(k->buf));
             if (k->flag) free_flags.push_back(std::move(k->flag));
+            k->w = nullptr;
         }
     }
     void push(int kind, uint64_t v) {
@@ -289,7 +309,7 @@ struct Streaming {
         if (t.first == 0) {
             Chunk* k = chunk((size_t)t.second);
             k->flag = take_flags();
-            k->count = flag_groups(k->w.get(), kChunkGroups, k->flag.get());
+            k->count = temper_and_flag(k->w, kChunkGroups, k->flag.get());
             k->state.store(2, std::memory_order_release);
             { std::lock_guard<std::mutex> l(qm); }
             qcv.notify_all();
@@ -335,7 +355,7 @@ struct Streaming {
             const size_t c = (size_t)(g / kChunkGroups);
             Chunk* k = chunk(c);
             const size_t a = (size_t)(g % kChunkGroups), b = (size_t)std::min<uint64_t>(kChunkGroups, a + (gend - g));
-            const uint32_t* w = k->w.get();
+            const uint32_t* w = k->w;
             const uint8_t* f = k->flag.get();
             for (size_t q = a; q < b; ++q) {
                 if (!f[q]) continue;
@@ -356,7 +376,7 @@ struct Streaming {
             Chunk* k = chunk(c);
             const size_t a = (size_t)(wpos % kChunkWords);
             const size_t m = std::min(left, (kChunkWords - a) / 2);
-            const uint32_t* w = k->w.get() + a;
+            const uint32_t* w = k->w + a;
             for (size_t q = 0; q < m; ++q) ou[u + q] = to_double(w[2 * q], w[2 * q + 1]);
             u += m; left -= m; wpos += 2 * m;
         }
@@ -368,34 +388,33 @@ struct Streaming {
     }
 };
 
-// tempered words into chunk after chunk until told to stop (the only sequential part of the whole draw)
+// raw words into chunk after chunk until told to stop: the only sequential part of the whole draw, and nothing but the
+// recurrence (0.25 ns per word; tempering is the flag task's)
 void generate(Streaming* S, const uint32_t* key0, int pos0) try {
-    uint32_t a[kN], b[kN];
-    uint32_t* cur = a;
-    uint32_t* nxt = b;
-    std::memcpy(cur, key0, sizeof(a));
-    int rp = pos0;
+    std::unique_ptr<Chunk> k = std::make_unique<Chunk>();
+    k->buf = S->take_words();
+    k->w = k->buf.get() + kN;
+    // chunk 0: the caller's block lies so that key0[pos0] is the chunk's first word; what it still holds needs no generating
+    std::memcpy(k->history, key0, sizeof(k->history));
+    std::memcpy(k->buf.get() + (kN - pos0), key0, sizeof(uint32_t) * kN);
+    size_t j0 = (size_t)(2 * kN - pos0);
     for (size_t c = 0; !S->stop.load(std::memory_order_acquire); ++c) {
         while (c >= S->walk_chunk.load(std::memory_order_acquire) + kMaxAhead && !S->stop.load(std::memory_order_acquire))
             std::this_thread::sleep_for(std::chrono::microseconds(50));      // far ahead of the walk: rare, and no hurry
         if (S->stop.load(std::memory_order_acquire)) break;
-        auto k = std::make_unique<Chunk>();
-        k->w = S->take_words();
-        if (rp == kN) { mt_next_block(cur, nxt); std::swap(cur, nxt); rp = 0; }
-        std::memcpy(k->snap_key, cur, sizeof(k->snap_key));
-        k->snap_pos = rp;
-        size_t filled = 0;
-        while (filled < kChunkWords) {
-            if (rp == kN) { mt_next_block(cur, nxt); std::swap(cur, nxt); rp = 0; }
-            const size_t m = std::min(kChunkWords - filled, (size_t)(kN - rp));
-            temper_block(cur + rp, k->w.get() + filled, m);
-            filled += m;
-            rp += (int)m;
-        }
+        mt_stream(k->buf.get(), j0, kN + kChunkWords);
+        // the next chunk's history is this chunk's raw tail: taken before the flag task tempers it
+        std::unique_ptr<Chunk> nx = std::make_unique<Chunk>();
+        nx->buf = S->take_words();
+        nx->w = nx->buf.get() + kN;
+        std::memcpy(nx->buf.get(), k->buf.get() + kChunkWords, sizeof(uint32_t) * kN);
+        std::memcpy(nx->history, nx->buf.get(), sizeof(nx->history));
         k->state.store(1, std::memory_order_release);
         { std::lock_guard<std::mutex> l(S->cm); S->chunks.push_back(std::move(k)); }
         S->generated.store(c + 1, std::memory_order_release);
         S->push(0, c);
+        k = std::move(nx);
+        j0 = kN;
     }
 } catch (...) {
     S->failed.store(true);
@@ -475,19 +494,28 @@ int scan_streaming(lrc_mt19937_state* st, uint64_t num_poses, uint64_t normals_p
     gen.join();
     for (auto& t : pool) t.join();
     if (bad || S.failed.load()) throw std::bad_alloc();
-    // the generator state numpy would be left with: key = the raw block of the last word consumed, pos = one past it
+    // the generator state numpy would be left with: key = numpy's block of the last word consumed, pos = one past it.  numpy's
+    // block b holds the words [624 b - pos0, 624 (b + 1) - pos0) of this call's stream; block 0 is the caller's key.
     const uint64_t W = 4 * G;
     if (W) {
-        const size_t c = (size_t)((W - 1) / kChunkWords);
-        Chunk* k = S.chunk(c);
-        const uint64_t idx = (uint64_t)k->snap_pos + ((W - 1) - (uint64_t)c * kChunkWords);
-        uint32_t a[kN], b[kN];
-        uint32_t* cur = a;
-        uint32_t* nxt = b;
-        std::memcpy(cur, k->snap_key, sizeof(a));
-        for (uint64_t s = 0; s < idx / kN; ++s) { mt_next_block(cur, nxt); std::swap(cur, nxt); }
-        std::memcpy(st->key, cur, sizeof(a));
-        st->pos = (int)(idx % kN) + 1;
+        const uint64_t pos0 = (uint64_t)st->pos, L = W - 1, blk = (L + pos0) / kN;
+        if (blk) {
+            const uint64_t bs = blk * kN - pos0;                   // stream offset of the block's first word
+            const size_t c = (size_t)(bs / kChunkWords);
+            Chunk* k = S.chunk(c);
+            const size_t need = (size_t)(bs - (uint64_t)c * kChunkWords) + 2 * kN;      // words of scratch incl. the history
+            std::vector<uint32_t> scratch(need + kN);
+            size_t j0 = kN;
+            if (c == 0) {
+                std::memcpy(scratch.data() + (kN - pos0), k->history, sizeof(uint32_t) * kN);
+                j0 = (size_t)(2 * kN - pos0);
+            } else {
+                std::memcpy(scratch.data(), k->history, sizeof(uint32_t) * kN);
+            }
+            if (need > j0) mt_stream(scratch.data(), j0, need);
+            std::memcpy(st->key, scratch.data() + (need - kN), sizeof(uint32_t) * kN);
+        }
+        st->pos = (int)((L + pos0) % kN) + 1;
     }
     st->has_gauss = 0;
     st->gauss = 0.0;

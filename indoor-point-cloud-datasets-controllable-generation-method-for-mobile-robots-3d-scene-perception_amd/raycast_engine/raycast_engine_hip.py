@@ -61,7 +61,7 @@ _RAY_POOL = None
 # threads of the native draws of the seeded stream: one generates words, the others flag and transform; the pool below
 # (numpy trigonometry, pose by pose) needs cores beside them
 import os as _os
-_DRAW_THREADS = int(_os.environ.get("LRC_DRAW_THREADS", "4"))
+_DRAW_THREADS = int(_os.environ.get("LRC_DRAW_THREADS", "8"))
 
 
 def _ray_pool():
@@ -121,7 +121,7 @@ def dual_axis_rays_batch(lidars, rays, keep):
 
         native_out = rays.dtype == np.float32 and rays[0].flags.c_contiguous
         one = _pose_rays_native if native_out else _pose_rays_numpy
-        run = 16
+        run = 32
         for a in range(0, P, run):
             b = min(P, a + run)
             z, u = nprandom.scan_draws(b - a, nn, nu, 0.0, k0.angle_noise_std, rng=rng, threads=_DRAW_THREADS)

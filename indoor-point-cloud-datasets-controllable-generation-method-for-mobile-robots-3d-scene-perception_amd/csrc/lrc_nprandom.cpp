@@ -332,6 +332,19 @@ struct Streaming {
         run(t);
         return true;
     }
+    // the calling thread sleeps until there is a task to help with, `ready` holds, or something failed.  Every state change
+    // it can wait for is followed by a lock / unlock of qm and a notify_all (run, push), so no wake-up is lost; the time-out
+    // is a safety net only (and absent from the ThreadSanitizer build, whose runtime does not know pthread_cond_clockwait).
+    template <class Ready>
+    void wait_until(Ready ready) {
+        std::unique_lock<std::mutex> l(qm);
+        auto pred = [&] { return failed.load() || !tasks.empty() || ready(); };
+#ifdef LRC_TSAN
+        qcv.wait(l, pred);
+#else
+        qcv.wait_for(l, std::chrono::milliseconds(2), pred);
+#endif
+    }
     void worker() {
         for (;;) {
             std::pair<int, uint64_t> t;
@@ -439,10 +452,7 @@ int scan_streaming(lrc_mt19937_state* st, uint64_t num_poses, uint64_t normals_p
                 Chunk* k = S.chunk(c);
                 if (k->state.load(std::memory_order_acquire) == 2) return k;
             }
-            if (!S.help()) {
-                std::unique_lock<std::mutex> l(S.qm);
-                S.qcv.wait_for(l, std::chrono::microseconds(200));
-            }
+            if (!S.help()) S.wait_until([&] { return c < S.generated.load(std::memory_order_acquire) && S.chunk(c)->state.load(std::memory_order_acquire) == 2; });
         }
     };
     uint64_t G = 0;                                      // group cursor
@@ -482,10 +492,7 @@ int scan_streaming(lrc_mt19937_state* st, uint64_t num_poses, uint64_t normals_p
     S.stop.store(true, std::memory_order_release);
     while (S.poses_done.load() < num_poses) {
         if (S.failed.load()) throw std::bad_alloc();
-        if (!S.help()) {
-            std::unique_lock<std::mutex> l(S.qm);
-            S.qcv.wait_for(l, std::chrono::microseconds(200));
-        }
+        if (!S.help()) S.wait_until([&] { return S.poses_done.load() >= num_poses; });
     }
     } catch (...) { bad = true; }
     S.stop.store(true, std::memory_order_release);

@@ -643,7 +643,11 @@ extern "C" int lrc_rng_scan_draws(lrc_mt19937_state* st, uint64_t num_poses, uin
     int nthreads = threads > 0 ? threads : (int)std::min<unsigned>(hw ? hw : 1u, 16u);
     // threads < 0: the sequential path with |threads| threads (tests compare the two paths)
     const bool aligned = normals_per_pose % 2 == 0 && uniforms_per_pose % 2 == 0 && !st->has_gauss;
-    if (threads >= 0 && aligned && nthreads >= 3 && num_poses * (normals_per_pose + uniforms_per_pose) >= (1u << 16)) {
+    // the streaming path pays when there are poses to hand out and normals to find the ends of: a trajectory of sensor-sized
+    // poses; few huge poses, uniforms only or thousands of tiny poses are quicker on the sequential path
+    const bool shaped = num_poses >= 4 && normals_per_pose >= 2 && normals_per_pose + uniforms_per_pose >= 4096 &&
+                        num_poses * (normals_per_pose + uniforms_per_pose) >= (1u << 16);
+    if (threads >= 0 && aligned && nthreads >= 3 && shaped) {
         try {
             return scan_streaming(st, num_poses, normals_per_pose, uniforms_per_pose, loc, scale, out_normals, out_uniforms, nthreads);
         } catch (const std::bad_alloc&) {

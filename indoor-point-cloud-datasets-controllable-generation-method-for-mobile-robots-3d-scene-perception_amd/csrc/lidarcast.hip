@@ -258,7 +258,10 @@ __device__ __forceinline__ void rebuild_tiles(const RebuildParams& q, uint32_t t
         dst[k] = 0;
         if (keep[k]) {
             const uint32_t tile = tile0 + k;
-            dst[k] = q.super_base[tile >> 10] + q.tile_off[tile] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+            // the tile's offset is wave-uniform too (written by the scan kernel before this launch): scalar loads
+            typedef __attribute__((address_space(4))) const uint64_t cu64;
+            typedef __attribute__((address_space(4))) const uint32_t cu32;
+            dst[k] = ((cu64*)q.super_base)[tile >> 10] + ((cu32*)q.tile_off)[tile] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
             da[k] = q.dirs_soa[idx[k]];
             db[k] = q.dirs_soa[(size_t)q.seg_len + idx[k]];
             dc[k] = q.dirs_soa[2 * (size_t)q.seg_len + idx[k]];
@@ -271,7 +274,10 @@ __device__ __forceinline__ void rebuild_tiles(const RebuildParams& q, uint32_t t
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         if (!keep[k]) continue;
-        const double* M = q.poses16 + (size_t)seg[k] * 16;
+        // the tile's pose is wave-uniform: its matrix comes through the scalar cache (constant address space), not as twelve
+        // 64-lane loads of one address through the vector memory path, which is what bounds this kernel
+        typedef __attribute__((address_space(4))) const double cdouble;
+        cdouble* M = (cdouble*)(q.poses16 + (size_t)seg[k] * 16);
         // gen_ray, with the direction already in registers (same FMA chain, lrc_device.h)
         V3 o, d, h, pt;
         d.x = (float)dgemm_row(da[k], db[k], dc[k], M[0], M[1], M[2]);

@@ -110,6 +110,20 @@ int lrc_ctx_create(int device, lrc_ctx** out_ctx);
 int lrc_ctx_destroy(lrc_ctx* ctx);
 int lrc_ctx_synchronize(lrc_ctx* ctx);
 
+/* Launch chaining (on by default where the device supports stream memory operations).
+ * The poses of a trajectory are independent (s3dis_simulator.py:254-288 carries no state from one waypoint to the
+ * next), so a caller may keep two scans in flight: lrc_scan_poses_dev / lrc_scan_angles_dev / lrc_cast*_dev on two
+ * streams with two record sets.  A scan launch ends in a tail -- a few long-running waves on an emptying chip -- and what
+ * two unordered launches make of it is luck: side by side they end together (nothing gained) or staggered (+12 %).
+ * With chaining the library orders them: a scan enqueued on ANOTHER stream than the previous scan of this context is held
+ * (hipStreamWaitValue64 on a signal word the previous launch's last workgroup writes when it starts) until that launch
+ * has no workgroup left to hand out, and then fills the slots its tail leaves empty.  Consecutive scans on ONE stream
+ * are untouched (stream order already serialises them).  The only semantic effect is an extra ordering edge from the
+ * earlier-enqueued scan to the later one; results are unaffected.  Switch it off for a caller whose other stream is
+ * blocked behind work that may not finish before this stream is needed. */
+int lrc_ctx_set_launch_chaining(lrc_ctx* ctx, int enabled);
+int lrc_ctx_get_launch_chaining(const lrc_ctx* ctx, int* out_enabled, int* out_supported);
+
 /* Build the scene once per mesh: float32 vertices (V,3) and uint32 triangle rows (T,3) in, binned-SAH
  * BVH (leaves <= 4 triangles, bounded depth), triangle records, id / label / plane tables and the
  * quantised node images out, all resident in HBM.  tri_sem / tri_ins are optional per-triangle labels.
@@ -228,6 +242,38 @@ int lrc_compact(lrc_ctx* ctx, uint64_t num_segments, uint64_t seg_len,
                 const lrc_compact_io* io, uint64_t* out_total);
 int lrc_compact_dev(lrc_ctx* ctx, uint64_t num_segments, uint64_t seg_len,
                     const lrc_compact_io* d_io, void* stream);
+
+/* ---- the scan pipeline: consecutive pose batches of one scene, launches overlapped inside the library ---------------
+ * The poses of a trajectory are independent (s3dis_simulator.py:254-288), and so are consecutive trajectories over one
+ * mesh (the reference's batch driver, s3dis_simulator.py:594-726, runs them one after the other).  A caller that stays on
+ * the device -- dataset generation, the multi-GPU step, bench.py -- submits batch after batch; each submit is one pose-batched
+ * scan (lrc_scan_poses_dev: the complete 36-byte record per ray, into one of four record sets the pipeline owns) plus the
+ * stable compaction (lrc_compact_dev) into the CALLER's rows / counts.  The pipeline arranges the launches so that the trace
+ * of submit k+1 fills the wave slots the trace of submit k leaves empty while its last, long-running waves finish, and the
+ * rows of submit k are scattered by the first workgroups of the trace launch of submit k+2 (DESIGN.md "the launch tail":
+ * a 64-pose launch alone loses a sixth of its time to that tail).  Same arithmetic, same bytes as lrc_scan_poses_dev +
+ * lrc_compact_dev called one after the other.
+ *   lrc_pipe_submit   enqueues only.  Inputs and the output buffers are taken as of `stream`'s current position; nothing
+ *                     is ordered after it on `stream` -- that is the point -- until
+ *   lrc_pipe_wait     scatters the rows still in the pipeline and makes `stream` wait for every submit so far (event
+ *                     waits, no host synchronisation).  Outputs of a submit are complete once `stream` has passed it.
+ *   d_out             the out_* members and counts of lrc_compact_io (device pointers); the input members are ignored.
+ *                     The buffers of a submit are written up to two submits later: rotate at least three output buffers
+ *                     between lrc_pipe_wait calls.  rays_per_pose % 64 != 0 falls back to scan + compaction per stream.
+ *   lrc_pipe_records  the fixed-stride records (lrc_hits, device pointers, tile_count included) of submit `ticket`;
+ *                     valid until three further submits have been made (four sets rotate).
+ *   lrc_pipe_trace_ms the time the trace launch of submit `ticket` spent between its stream reaching it and its last wave
+ *                     (HIP events on the launch stream; inside the pipeline launches overlap, so this is longer than the
+ *                     launch's share of the step).  Synchronises the host with that launch.
+ * Destroy the pipeline before its scene. */
+typedef struct lrc_pipe lrc_pipe;
+int lrc_pipe_create(lrc_scene* scene, uint64_t max_poses, uint64_t rays_per_pose, lrc_pipe** out_pipe);
+int lrc_pipe_destroy(lrc_pipe* pipe);
+int lrc_pipe_submit(lrc_pipe* pipe, const double* d_poses16, uint64_t num_poses, const double* d_dirs3, double max_range,
+                    const lrc_compact_io* d_out, void* stream, uint64_t* out_ticket);
+int lrc_pipe_wait(lrc_pipe* pipe, void* stream);
+int lrc_pipe_records(lrc_pipe* pipe, uint64_t ticket, lrc_hits* out_records);
+int lrc_pipe_trace_ms(lrc_pipe* pipe, uint64_t ticket, float* out_ms);
 
 /* ---- scan straight to the reference's variable-length frames ---------------------------------------
  * What S3DISSimulator.run_simulation needs from a whole trajectory (s3dis_simulator.py:254-288): per pose the kept

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -93,7 +94,24 @@ struct lrc_ctx {
         double* d_dirs_soa = nullptr;       // direction table transposed to x[N] y[N] z[N] (cloud rebuild only)
         uint64_t dirs_cap = 0;
     };
-    TileScratch compact_scratch, cloud_scratch;
+    TileScratch cloud_scratch;
+    // lrc_compact_dev: one scratch set per caller stream (a caller that keeps two scans in flight on two streams compacts on
+    // both); a set handed on to another stream is first ordered behind its last use (scratch_for)
+    static constexpr int kCompactSets = 4;
+    TileScratch compact_scratch[kCompactSets];
+    hipStream_t compact_stream[kCompactSets] = {};
+    hipEvent_t compact_done[kCompactSets] = {};
+    bool compact_used[kCompactSets] = {};
+    int compact_next = 0;
+    // Dispatch chaining of trace launches ("the launch tail"): the LAST workgroup of every trace launch writes the
+    // launch's sequence number to this signal word at its first instruction; a trace launch on ANOTHER stream than the
+    // previous one is held behind hipStreamWaitValue64(word >= previous sequence number), i.e. it starts the moment the
+    // previous launch has handed out its last workgroup -- its waves fill the slots the previous launch's tail leaves empty,
+    // and launches that a caller keeps in flight on two streams run staggered instead of falling into phase.
+    uint64_t* chain_word = nullptr;     // hipMallocSignalMemory; NULL: not supported here, launches are never chained
+    uint64_t chain_seq = 0;             // sequence number of the last chained trace launch
+    hipStream_t chain_stream = nullptr; // ... and the stream it went to
+    bool chain_enabled = true;          // lrc_ctx_set_launch_chaining
     // *_compact entry points: kernels on one stream, the transfers of finished pose chunks on another
     hipStream_t s_compute = nullptr, s_copy = nullptr, s_stats = nullptr;
     hipEvent_t ev_chunk[8] = {}, ev_compact[8] = {};
@@ -117,6 +135,7 @@ struct lrc_scene {
     uint32_t* d_slot_label = nullptr;
     float* d_slot_box = nullptr;      // per leaf slot the triangle's exact vertex box (lo xyz, hi xyz)
     float4* d_prim_plane = nullptr;   // per caller's triangle row: (v0, label bits), (Ng, 0): lrc_cloud_from_prims_dev
+    std::mutex plane_mutex;           // ... built on first use, published complete (ensure_prim_plane)
     float4* d_slot_sphere = nullptr;  // per leaf slot: centre of the triangle's box + bounding radius (sector_kernel)
     // quantised node images of the SAME tree ("32-byte nodes"): child boxes on a 15-bit grid
     // per axis, rounded outward (margin 1/16 cell).  d_nodes_q: 32 B per node for the per-lane fetches; d_nodes_n: the same
@@ -172,6 +191,20 @@ struct TraceParams {
     uint32_t stack_cap;        // entries of the per-lane LDS stack
     uint32_t tile_chunk_log2;  // 0: eight contiguous tile ranges, one per XCD; k + 1: chunks of 2^k tiles round robin
     uint32_t force_redo;       // test hook (LRC_DEBUG_FORCE_REDO=m): rays with gid % m == 0 take the redo path as well
+    uint64_t* chain_word;      // launch chain (lrc_ctx::chain_word): the last workgroup stores chain_seq here when it starts
+    uint64_t chain_seq;
+    // scan pipeline (lrc_pipe): the first pre.blocks workgroups of the launch do not trace -- each compacts one 64-entry
+    // tile of an EARLIER scan's records (whose offsets a scan pass has tabulated).  They are handed out first, i.e. into the
+    // wave slots the previous launch's long last waves leave empty, and are gone in microseconds; the trace tiles follow in
+    // the same grid with no barrier in between.
+    struct Pre {
+        uint32_t blocks;           // each takes kPreTiles tiles
+        uint32_t rows_only;        // only the packed (x, y, z, label) rows (+ counts) are asked for: the batched form
+        uint64_t seg_len, tps, ntiles, nseg;
+        const uint32_t* tile_off;
+        const uint32_t* super_total;
+        lrc_compact_io io;
+    } pre;
     float qbase[3], qW[3], qinvW[3];   // normalised coordinate n = (x - qbase) * qinvW in [2, 4); qW = 1 / qinvW = 2^k
     // inputs
     const float* rays6;        // explicit rays (GEN = false)
@@ -392,6 +425,121 @@ __device__ __forceinline__ void write_back(const TraceParams& p, uint64_t gid, u
 
 constexpr int kStatsWords = 5;   // node steps, triangle tests, wave-uniform node steps, dead node steps, pad-clause rejections
 
+// ---- stable compaction, one tile (64 consecutive entries of one segment) per wave ---------------------------------------
+// exclusive prefix of the super-tile totals at super tile s, formed on the spot: a wave sums at most a few hundred
+// numbers, which is cheaper than the launch of a kernel that would tabulate them (compact_base_kernel)
+__device__ __forceinline__ uint64_t super_prefix_wave(const uint32_t* __restrict__ total, uint64_t s, uint32_t lane) {
+    uint64_t acc = 0;
+    for (uint64_t j = lane; j < s; j += 64) acc += total[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    return acc;
+}
+__device__ __forceinline__ uint64_t super_prefix_thread(const uint32_t* __restrict__ total, uint64_t s) {
+    uint64_t acc = 0;
+    for (uint64_t j = 0; j < s; ++j) acc += total[j];
+    return acc;
+}
+
+// one thread per segment: count = global offset of its end tile - global offset of its first tile
+__device__ __forceinline__ void segment_count(const lrc_compact_io& io, uint64_t tps, uint64_t ntiles, uint64_t nseg, uint64_t sg,
+                                              const uint32_t* tile_off, const uint64_t* super_base, const uint32_t* super_total) {
+    if (sg >= nseg) return;
+    const uint64_t nsuper = (ntiles + 1023) / 1024;
+    const uint64_t g0 = sg * tps, g1 = g0 + tps;
+    auto at = [&](uint64_t g) -> uint64_t {
+        if (super_total) return g >= ntiles ? super_prefix_thread(super_total, nsuper)
+                                            : super_prefix_thread(super_total, g >> 10) + tile_off[g];
+        return g >= ntiles ? super_base[nsuper] : super_base[g >> 10] + tile_off[g];
+    };
+    io.counts[sg] = at(g1) - at(g0);
+}
+
+// the kept entries of tile `tile` go to their rows; called by all 64 lanes of one wave
+__device__ __forceinline__ void scatter_tile(const lrc_compact_io& io, uint64_t seg_len, uint64_t tps, uint64_t tile, uint32_t lane,
+                                             const uint32_t* tile_off, const uint64_t* super_base, uint64_t tile_base,
+                                             const uint32_t* super_total) {
+    const uint64_t seg = tile / tps, chunk = tile - seg * tps;
+    const uint64_t i = chunk * 64 + lane;
+    const uint64_t src = seg * seg_len + i;
+    bool keep = false;
+    if (i < seg_len) keep = io.t[src] < __builtin_inff();
+    const unsigned long long m = __ballot(keep);
+    if (m == 0ull) return;
+    const uint64_t gt = tile_base + tile;
+    const uint64_t sbase = super_total ? super_prefix_wave(super_total, gt >> 10, lane) : super_base[gt >> 10];
+    if (!keep) return;
+    const uint64_t tbase = sbase + tile_off[gt];
+    const uint64_t dst = tbase + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (io.out_xyzl) {
+        const float* sp = io.point3 + src * 3;
+        const uint32_t lab = (io.sem ? (uint32_t)io.sem[src] : 0u) | ((io.ins ? (uint32_t)io.ins[src] : 0u) << 16);
+        ((float4*)io.out_xyzl)[dst] = make_float4(sp[0], sp[1], sp[2], __uint_as_float(lab));
+    }
+    if (io.out_point3) {
+        const float* sp = io.point3 + src * 3;
+        float* q = io.out_point3 + dst * 3;
+        q[0] = sp[0]; q[1] = sp[1]; q[2] = sp[2];
+    }
+    if (io.out_sem) io.out_sem[dst] = io.sem[src];
+    if (io.out_ins) io.out_ins[dst] = io.ins[src];
+    if (io.out_incident_deg) io.out_incident_deg[dst] = io.incident_deg[src];
+    if (io.out_index) io.out_index[dst] = (uint32_t)i;
+    if (io.out_range_origin) {
+        // |p| from the WORLD origin in float32 exactly as np.linalg.norm(points, axis=1) forms it: squares, the
+        // 3-element add.reduce left to right, one sqrt -- the quantity the reference's ScanQuality range statistics are
+        // taken over (s3dis_simulator.py:283-284)
+        const float* sp = io.point3 + src * 3;
+        io.out_range_origin[dst] = __builtin_sqrtf((sp[0] * sp[0] + sp[1] * sp[1]) + sp[2] * sp[2]);
+    }
+}
+
+// R consecutive tiles by one wave, packed (x, y, z, label) rows only, tiles aligned with the segments (seg_len % 64 == 0) and R
+// dividing 1024 (the tiles of a call lie in one super tile).  This is the form the trace launch of the scan pipeline runs in
+// its leading workgroups: a wave there holds a trace wave's registers and LDS, so few waves with many loads in flight each --
+// all keep flags first, then all payloads, then the stores: two memory round trips per R tiles instead of per tile.
+template <int R>
+__device__ __forceinline__ void scatter_tiles_xyzl(const lrc_compact_io& io, uint64_t ntiles, uint64_t tile0, uint32_t lane,
+                                                   const uint32_t* tile_off, const uint32_t* super_total) {
+    float t[R];
+    uint32_t off[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint64_t tile = tile0 + r;
+        const bool valid = tile < ntiles;
+        t[r] = valid ? io.t[tile * 64 + lane] : __builtin_inff();
+        off[r] = valid ? tile_off[tile] : 0u;
+    }
+    const uint64_t sbase = super_prefix_wave(super_total, tile0 >> 10, lane);
+    float px[R], py[R], pz[R];
+    uint32_t lab[R];
+    unsigned long long m[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool keep = t[r] < __builtin_inff();
+        m[r] = __ballot(keep);
+        px[r] = py[r] = pz[r] = 0.0f;
+        lab[r] = 0u;
+        if (keep) {
+            const uint64_t src = (tile0 + r) * 64 + lane;
+            const float* sp = io.point3 + src * 3;
+            px[r] = sp[0]; py[r] = sp[1]; pz[r] = sp[2];
+            lab[r] = (io.sem ? (uint32_t)io.sem[src] : 0u) | ((io.ins ? (uint32_t)io.ins[src] : 0u) << 16);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (t[r] < __builtin_inff()) {
+            const uint64_t dst = sbase + off[r] + (uint64_t)__popcll(m[r] & ((1ull << lane) - 1ull));
+            ((float4*)io.out_xyzl)[dst] = make_float4(px[r], py[r], pz[r], __uint_as_float(lab[r]));
+        }
+    }
+}
+#ifndef LRC_PRE_TILES
+#define LRC_PRE_TILES 8
+#endif
+constexpr int kPreTiles = LRC_PRE_TILES;      // tiles per leading workgroup of a pipelined trace launch (4 / 8 / 16 measured)
+
 template <int I> struct IntTag { static constexpr int value = I; };
 
 // GEN: 0 = explicit rays, 1 = pose x direction table, 2 = pose x per-ray scan angles (dual-axis sensor, opt-in)
@@ -402,9 +550,30 @@ template <int GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false, int QN = 
 __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) void trace_kernel(const TraceParams p) {
     extern __shared__ int s_stack[];   // [stack depth][kTBlock]: one column per lane, conflict free
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile = p.tile_chunk_log2 ? xcd_tile_chunked(blockIdx.x, gridDim.x, p.tile_chunk_log2)
-                                            : xcd_tile(blockIdx.x, gridDim.x);
+    if (GEN == 1 && p.pre.blocks != 0u) {          // wave-uniform; only the pose-batched scan is ever pipelined
+        if (blockIdx.x < p.pre.blocks) {
+            if (p.pre.io.counts) segment_count(p.pre.io, p.pre.tps, p.pre.ntiles, p.pre.nseg, (uint64_t)blockIdx.x * kTBlock + tid,
+                                               p.pre.tile_off, nullptr, p.pre.super_total);
+            const uint64_t tile0 = (uint64_t)blockIdx.x * kPreTiles;
+            if (tile0 < p.pre.ntiles) {
+                if (p.pre.rows_only) {
+                    scatter_tiles_xyzl<kPreTiles>(p.pre.io, p.pre.ntiles, tile0, tid, p.pre.tile_off, p.pre.super_total);
+                } else {
+                    for (int r = 0; r < kPreTiles; ++r)
+                        if (tile0 + r < p.pre.ntiles)
+                            scatter_tile(p.pre.io, p.pre.seg_len, p.pre.tps, tile0 + r, tid, p.pre.tile_off, nullptr, 0, p.pre.super_total);
+                }
+            }
+            return;
+        }
+    }
+    const uint32_t tile = p.tile_chunk_log2 ? xcd_tile_chunked(blockIdx.x - p.pre.blocks, gridDim.x - p.pre.blocks, p.tile_chunk_log2)
+                                            : xcd_tile(blockIdx.x - p.pre.blocks, gridDim.x - p.pre.blocks);
     const uint64_t gid = (uint64_t)tile * kTBlock + tid;
+    // launch chain: workgroups are handed out in blockIdx order, so when the last one starts the launch has no workgroup
+    // left to dispatch -- the next trace launch (held on another stream behind this word) may start filling the freed slots
+    if (p.chain_word != nullptr && blockIdx.x == gridDim.x - 1 && tid == 0)
+        __hip_atomic_store(p.chain_word, p.chain_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (gid >= p.total) return;
 
     // ---- the ray ----
@@ -768,7 +937,8 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
     // the workgroup number is made opaque so that the two computations are not merged
     uint32_t wg = blockIdx.x;
     asm volatile("" : "+s"(wg));
-    const uint32_t tile_w = p.tile_chunk_log2 ? xcd_tile_chunked(wg, gridDim.x, p.tile_chunk_log2) : xcd_tile(wg, gridDim.x);
+    const uint32_t tile_w = p.tile_chunk_log2 ? xcd_tile_chunked(wg - p.pre.blocks, gridDim.x - p.pre.blocks, p.tile_chunk_log2)
+                                              : xcd_tile(wg - p.pre.blocks, gridDim.x - p.pre.blocks);
     const uint64_t gid_w = (uint64_t)tile_w * kTBlock + tid;
     write_back<GEN != 0>(p, gid_w, tid, o, d, cx, cy, cz, tbest, best_slot);
     if (STATS) {
@@ -940,79 +1110,79 @@ __global__ __launch_bounds__(kBlock) void compact_count_kernel(const float* t, u
     if ((threadIdx.x & 63u) == 0) tile_cnt[tile] = (uint32_t)__popcll(m);
 }
 
-// Pass A: every workgroup scans its own run of 1024 tile counts (a "super tile" = 65536 entries):
+// Pass A: one WAVE scans a run of 1024 tile counts (a "super tile" = 65536 entries):
 // tile_off[tile] = exclusive offset inside the super tile, super_total[b] = its sum.
 // The counts may sit in slabs (the gathered send buffers of several ranks): tiles_per_slab consecutive tiles, then the
 // next slab slab_stride words further on; a plain array is one slab.
-__global__ __launch_bounds__(1024) void compact_scan_kernel(const uint32_t* tile_cnt, uint64_t tiles_per_slab,
-                                                            uint64_t slab_stride, uint32_t* tile_off,
-                                                            uint64_t ntiles, uint32_t* super_total) {
-    __shared__ uint32_t s_wave[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const uint64_t tile = (uint64_t)blockIdx.x * 1024 + tid;
-    uint32_t c = 0u;
-    if (tile < ntiles) {
-        const uint64_t sb = tile / tiles_per_slab;
-        c = tile_cnt[sb * slab_stride + (tile - sb * tiles_per_slab)];
-    }
-    uint32_t incl = c;                       // inclusive scan inside the wave
+// One-wave workgroups on purpose: this kernel runs beside the trace launch of the caller's other stream, which takes every
+// wave slot the moment it is freed.  As a 1024-thread workgroup (16 waves that must start together on ONE CU) the scan
+// was not scheduled until that launch had no workgroup left -- 150-170 us for a 5 us kernel, and with it the whole chain
+// trace -> scan -> scatter -> next trace fell into phase with the other stream's (profiles/r04_chain_timeline.txt).
+constexpr int kScanRows = 16;           // 64 lanes x 16 rows = 1024 tiles per wave and super tile
+__global__ __launch_bounds__(64) void compact_scan_kernel(const uint32_t* tile_cnt, uint64_t tiles_per_slab,
+                                                          uint64_t slab_stride, uint32_t* tile_off,
+                                                          uint64_t ntiles, uint32_t* super_total) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t nsuper = (ntiles + 1023) / 1024;
+    const bool one_slab = tiles_per_slab >= ntiles;          // a plain array: no slab arithmetic (a 64-bit division per entry)
+    // grid-stride over the super tiles: the scan pipeline launches FEW waves on purpose (each must find a free wave slot
+    // beside a running trace launch, and they arrive at a trickle), stand-alone callers one wave per super tile
+    for (uint64_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
+        const uint64_t first = sup * 1024;
+        uint32_t c[kScanRows];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d, 64);
-        if (lane >= (uint32_t)d) incl += up;
-    }
-    if (lane == 63) s_wave[w] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t k = 0; k < w; ++k) base += s_wave[k];
-    if (tile < ntiles) tile_off[tile] = base + incl - c;
-    if (tid == 1023) super_total[blockIdx.x] = base + incl;
-}
-
-// Pass A2: one workgroup turns the super-tile totals into exclusive bases (base[nsuper] = grand total).
-__global__ __launch_bounds__(1024) void compact_base_kernel(const uint32_t* super_total, uint64_t* super_base,
-                                                            uint64_t nsuper) {
-    __shared__ uint64_t s_part[1024];
-    __shared__ uint64_t s_carry;
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (uint64_t base = 0; base < nsuper; base += 1024) {
-        const uint64_t i = base + tid;
-        const uint64_t v = i < nsuper ? super_total[i] : 0;
-        s_part[tid] = v;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            const uint64_t add = tid >= off ? s_part[tid - off] : 0;
-            __syncthreads();
-            s_part[tid] += add;
-            __syncthreads();
+        for (int r = 0; r < kScanRows; ++r) {          // all loads first (coalesced rows of 64), then the arithmetic
+            const uint64_t tile = first + (uint64_t)r * 64 + lane;
+            c[r] = 0u;
+            if (tile < ntiles) {
+                uint64_t idx = tile;
+                if (!one_slab) {
+                    const uint64_t sb = tile / tiles_per_slab;
+                    idx = sb * slab_stride + (tile - sb * tiles_per_slab);
+                }
+                c[r] = tile_cnt[idx];
+            }
         }
-        const uint64_t carry = s_carry;
-        if (i < nsuper) super_base[i] = carry + s_part[tid] - v;
-        __syncthreads();
-        if (tid == 1023) s_carry = carry + s_part[1023];
-        __syncthreads();
-    }
-    if (tid == 0) super_base[nsuper] = s_carry;
-}
-
-// Pass B: scatter the kept entries; the first workgroups also write the per-segment counts.
-// exclusive prefix of the super-tile totals at super tile s, formed on the spot: a wave sums at most a few hundred
-// numbers, which is cheaper than the launch of a kernel that would tabulate them (compact_base_kernel)
-__device__ __forceinline__ uint64_t super_prefix_wave(const uint32_t* __restrict__ total, uint64_t s, uint32_t lane) {
-    uint64_t acc = 0;
-    for (uint64_t j = lane; j < s; j += 64) acc += total[j];
+        uint32_t carry = 0u;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-    return acc;
-}
-__device__ __forceinline__ uint64_t super_prefix_thread(const uint32_t* __restrict__ total, uint64_t s) {
-    uint64_t acc = 0;
-    for (uint64_t j = 0; j < s; ++j) acc += total[j];
-    return acc;
+        for (int r = 0; r < kScanRows; ++r) {
+            uint32_t incl = c[r];                     // inclusive scan of the row inside the wave
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d, 64);
+                if (lane >= (uint32_t)d) incl += up;
+            }
+            const uint64_t tile = first + (uint64_t)r * 64 + lane;
+            if (tile < ntiles) tile_off[tile] = carry + incl - c[r];
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0) super_total[sup] = carry;
+    }
 }
 
+// Pass A2: one wave turns the super-tile totals into exclusive bases (base[nsuper] = grand total).  One wave for the same
+// reason as above: a 1024-thread workgroup waits for sixteen free wave slots on one CU while a trace launch is running.
+__global__ __launch_bounds__(64) void compact_base_kernel(const uint32_t* super_total, uint64_t* super_base,
+                                                          uint64_t nsuper) {
+    const uint32_t lane = threadIdx.x;
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < nsuper; base += 64) {
+        const uint64_t i = base + lane;
+        const uint64_t v = i < nsuper ? super_total[i] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t up = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d) incl += up;
+        }
+        if (i < nsuper) super_base[i] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) super_base[nsuper] = carry;
+}
+
+// Pass B: scatter the kept entries; the first workgroups also write the per-segment counts (scatter_tile / segment_count,
+// defined in front of the trace kernel, which runs them too: TraceParams::pre).
 // tile_base: index of this call's tile 0 in tile_off / super_base (non-zero when the offsets come from a scan over the
 // tiles of several ranks and this call scatters one rank's records into the assembled cloud).
 // super_total != NULL: the bases of the super tiles are summed here from the totals (super_base is not read).
@@ -1022,56 +1192,10 @@ __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const lrc_compa
                                                                  const uint32_t* tile_off,
                                                                  const uint64_t* super_base, uint64_t tile_base,
                                                                  const uint32_t* super_total) {
-    const uint32_t lane = threadIdx.x & 63u;
-    if (io.counts) {
-        // one thread per segment: count = global offset of its end tile - global offset of its first tile
-        const uint64_t sg = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-        if (sg < nseg) {
-            const uint64_t nsuper = (ntiles + 1023) / 1024;
-            const uint64_t g0 = sg * tps, g1 = g0 + tps;
-            auto at = [&](uint64_t g) -> uint64_t {
-                if (super_total) return g >= ntiles ? super_prefix_thread(super_total, nsuper)
-                                                    : super_prefix_thread(super_total, g >> 10) + tile_off[g];
-                return g >= ntiles ? super_base[nsuper] : super_base[g >> 10] + tile_off[g];
-            };
-            io.counts[sg] = at(g1) - at(g0);
-        }
-    }
+    if (io.counts) segment_count(io, tps, ntiles, nseg, (uint64_t)blockIdx.x * kBlock + threadIdx.x, tile_off, super_base, super_total);
     const uint64_t tile = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (tile >= ntiles) return;
-    const uint64_t seg = tile / tps, chunk = tile - seg * tps;
-    const uint64_t i = chunk * 64 + lane;
-    const uint64_t src = seg * seg_len + i;
-    bool keep = false;
-    if (i < seg_len) keep = io.t[src] < __builtin_inff();
-    const unsigned long long m = __ballot(keep);
-    if (m == 0ull) return;
-    const uint64_t gt = tile_base + tile;
-    const uint64_t sbase = super_total ? super_prefix_wave(super_total, gt >> 10, lane) : super_base[gt >> 10];
-    if (!keep) return;
-    const uint64_t tbase = sbase + tile_off[gt];
-    const uint64_t dst = tbase + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (io.out_xyzl) {
-        const float* sp = io.point3 + src * 3;
-        const uint32_t lab = (io.sem ? (uint32_t)io.sem[src] : 0u) | ((io.ins ? (uint32_t)io.ins[src] : 0u) << 16);
-        ((float4*)io.out_xyzl)[dst] = make_float4(sp[0], sp[1], sp[2], __uint_as_float(lab));
-    }
-    if (io.out_point3) {
-        const float* sp = io.point3 + src * 3;
-        float* q = io.out_point3 + dst * 3;
-        q[0] = sp[0]; q[1] = sp[1]; q[2] = sp[2];
-    }
-    if (io.out_sem) io.out_sem[dst] = io.sem[src];
-    if (io.out_ins) io.out_ins[dst] = io.ins[src];
-    if (io.out_incident_deg) io.out_incident_deg[dst] = io.incident_deg[src];
-    if (io.out_index) io.out_index[dst] = (uint32_t)i;
-    if (io.out_range_origin) {
-        // |p| from the WORLD origin in float32 exactly as np.linalg.norm(points, axis=1) forms it: squares, the
-        // 3-element add.reduce left to right, one sqrt -- the quantity the reference's ScanQuality range statistics are
-        // taken over (s3dis_simulator.py:283-284)
-        const float* sp = io.point3 + src * 3;
-        io.out_range_origin[dst] = __builtin_sqrtf((sp[0] * sp[0] + sp[1] * sp[1]) + sp[2] * sp[2]);
-    }
+    scatter_tile(io, seg_len, tps, tile, threadIdx.x & 63u, tile_off, super_base, tile_base, super_total);
 }
 
 // |p| of assembled (x, y, z, label) rows from the WORLD origin, float32, as np.linalg.norm(points, axis=1) forms it
@@ -1248,7 +1372,33 @@ int lrc_ctx_create(int device, lrc_ctx** out_ctx) {
     lrc_ctx* c = new (std::nothrow) lrc_ctx();
     if (!c) return fail(LRC_ERR_OOM, "lrc_ctx_create: out of host memory");
     c->device = device;
+    // the signal word of the launch chain; where stream memory operations are not available launches are simply not chained
+    int can_wait = 0;
+    if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can_wait) {
+        void* w = nullptr;
+        if (hipExtMallocWithFlags(&w, 8, hipMallocSignalMemory) == hipSuccess && w) {
+            if (hipStreamWriteValue64(nullptr, w, 0, 0) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess) {
+                c->chain_word = (uint64_t*)w;
+            } else {
+                (void)hipFree(w);
+            }
+        }
+    }
+    (void)hipGetLastError();
     *out_ctx = c;
+    return LRC_OK;
+}
+
+int lrc_ctx_set_launch_chaining(lrc_ctx* ctx, int enabled) {
+    if (!ctx) return fail(LRC_ERR_INVALID_ARG, "lrc_ctx_set_launch_chaining: ctx is NULL");
+    ctx->chain_enabled = enabled != 0;
+    return LRC_OK;
+}
+
+int lrc_ctx_get_launch_chaining(const lrc_ctx* ctx, int* enabled, int* supported) {
+    if (!ctx) return fail(LRC_ERR_INVALID_ARG, "lrc_ctx_get_launch_chaining: ctx is NULL");
+    if (enabled) *enabled = ctx->chain_enabled ? 1 : 0;
+    if (supported) *supported = ctx->chain_word ? 1 : 0;
     return LRC_OK;
 }
 
@@ -1264,7 +1414,10 @@ int lrc_ctx_destroy(lrc_ctx* ctx) {
     if (ctx->s_stats) (void)hipStreamDestroy(ctx->s_stats);
     for (hipEvent_t e : ctx->ev_chunk) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_compact) if (e) (void)hipEventDestroy(e);
-    for (lrc_ctx::TileScratch* sc : {&ctx->compact_scratch, &ctx->cloud_scratch}) {
+    if (ctx->chain_word) (void)hipFree(ctx->chain_word);
+    for (hipEvent_t e : ctx->compact_done) if (e) (void)hipEventDestroy(e);
+    for (lrc_ctx::TileScratch* sc : {&ctx->compact_scratch[0], &ctx->compact_scratch[1], &ctx->compact_scratch[2],
+                                     &ctx->compact_scratch[3], &ctx->cloud_scratch}) {
         if (sc->d_tile_off) (void)hipFree(sc->d_tile_off);
         if (sc->d_tile_cnt) (void)hipFree(sc->d_tile_cnt);
         if (sc->d_super_total) (void)hipFree(sc->d_super_total);
@@ -1550,17 +1703,32 @@ int lrc_scene_export_bvh(const lrc_scene* s, float* nodes16, uint32_t* slot_prim
     return LRC_OK;
 }
 
-// the plane table of the cloud rebuild, built on first use (enqueued on `st`)
+// the plane table of the cloud rebuild, built on first use.  The table is complete before the pointer is published (one
+// synchronisation, once per scene): a second caller -- another host thread, or another non-blocking stream -- either sees
+// NULL and waits for the mutex, or sees a finished table; it can never read a zeroed or half-written one.
 static int ensure_prim_plane(lrc_scene* s, hipStream_t st) {
-    if (s->d_prim_plane || s->info.num_triangles == 0) return LRC_OK;
+    if (s->info.num_triangles == 0) return LRC_OK;
+    if (__atomic_load_n(&s->d_prim_plane, __ATOMIC_ACQUIRE)) return LRC_OK;
+    std::lock_guard<std::mutex> lock(s->plane_mutex);
+    if (s->d_prim_plane) return LRC_OK;
     const uint64_t T = s->info.num_triangles;
-    LRC_HIP(hipMalloc((void**)&s->d_prim_plane, T * 32));
-    LRC_HIP(hipMemsetAsync(s->d_prim_plane, 0, T * 32, st));
-    hipLaunchKernelGGL(prim_plane_kernel, dim3((uint32_t)((s->info.num_slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                       (const float4*)s->d_tris, (const uint32_t*)s->d_slot_prim, (const uint32_t*)s->d_slot_label,
-                       (uint32_t)s->info.num_slots, (uint32_t)T, s->d_prim_plane);
-    LRC_HIP(hipGetLastError());
+    float4* table = nullptr;
+    LRC_HIP(hipMalloc((void**)&table, T * 32));
+    hipError_t e = hipMemsetAsync(table, 0, T * 32, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(prim_plane_kernel, dim3((uint32_t)((s->info.num_slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           (const float4*)s->d_tris, (const uint32_t*)s->d_slot_prim, (const uint32_t*)s->d_slot_label,
+                           (uint32_t)s->info.num_slots, (uint32_t)T, table);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        (void)hipFree(table);
+        (void)hipGetLastError();
+        return fail(LRC_ERR_HIP, std::string("plane table of the cloud rebuild: ") + hipGetErrorString(e));
+    }
     s->info.device_bytes += T * 32;
+    __atomic_store_n(&s->d_prim_plane, table, __ATOMIC_RELEASE);
     return LRC_OK;
 }
 
@@ -1712,7 +1880,7 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
     }
     if (p.total == 0) return LRC_OK;
     const uint64_t nblk = (p.total + kTBlock - 1) / kTBlock;
-    if (nblk > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "too many rays for one launch");
+    if (nblk + p.pre.blocks > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "too many rays for one launch");
     // stack entries needed = deepest leaf depth (one pending sibling per inner level above it)
     const uint32_t depth = s->info.max_depth < 1 ? 1 : s->info.max_depth;
     const size_t lds = (size_t)depth * kTBlock * sizeof(int);
@@ -1751,8 +1919,25 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
     }
 #endif
     if (gen == 3) gen = 1;
+    // Launch chain.  Every product trace launch signs the context's signal word when its last workgroup starts.  A launch
+    // that goes to ANOTHER stream than the previous one is held until that signature is there: the caller keeps two scans
+    // in flight (two streams, two record sets), so instead of both launches dispatching side by side and ending together --
+    // or, by chance, not -- this one starts exactly when the previous one has no workgroup left to hand out, and its waves
+    // fill the slots the previous launch's long-running last waves leave empty.  Same stream as before: stream order already
+    // serialises the two launches, nothing is added.  The wait only ever refers to a launch enqueued earlier, so it cannot
+    // close a cycle with the caller's own events.
+    lrc_ctx* const cx_ = s->ctx;
+    if (cx_->chain_word && cx_->chain_enabled) {
+        if (cx_->chain_seq > 0 && st != cx_->chain_stream && st != nullptr && cx_->chain_stream != nullptr)
+            LRC_HIP(hipStreamWaitValue64(st, cx_->chain_word, cx_->chain_seq, hipStreamWaitValueGte, ~0ull));
+        p.chain_word = cx_->chain_word;
+        p.chain_seq = cx_->chain_seq + 1;
+    } else {
+        p.chain_word = nullptr;
+        p.chain_seq = 0;
+    }
 #define LRC_LAUNCH(G, S, Q) \
-    hipLaunchKernelGGL((trace_kernel<G, kLeafW, true, false, S, Q>), dim3((uint32_t)nblk), dim3(kTBlock), lds, st, p)
+    hipLaunchKernelGGL((trace_kernel<G, kLeafW, true, false, S, Q>), dim3((uint32_t)(nblk + p.pre.blocks)), dim3(kTBlock), lds, st, p)
     if (stats) {   // per-ray traversal counters (lrc_debug_scan_stats)
         if (gen == 1) { if (qn) LRC_LAUNCH(1, true, 1); else LRC_LAUNCH(1, true, 0); }
         else if (gen == 0) { if (qn) LRC_LAUNCH(0, true, 1); else LRC_LAUNCH(0, true, 0); }
@@ -1762,6 +1947,7 @@ static int launch_trace(lrc_scene* s, TraceParams& p, int gen, hipStream_t st, b
     else { if (qn) LRC_LAUNCH(0, false, 1); else LRC_LAUNCH(0, false, 0); }
 #undef LRC_LAUNCH
     LRC_HIP(hipGetLastError());
+    if (p.chain_word) { cx_->chain_seq = p.chain_seq; cx_->chain_stream = st; }
     s->launches += 1;
     s->rays += p.total;
     return LRC_OK;
@@ -2018,6 +2204,38 @@ int lrc_scan_poses(lrc_scene* s, const double* poses16, uint64_t P, const double
 }
 
 static int ensure_tile_scratch(lrc_ctx* ctx, lrc_ctx::TileScratch& sc, uint64_t ntiles);
+static int compact_scratch_for(lrc_ctx* ctx, hipStream_t st, uint64_t ntiles, int* out_set);
+
+// the launches of a compaction on stream `st` with scratch set `sc` (sized by the caller for nseg * ceil(seg_len / 64) tiles)
+static int enqueue_compaction(lrc_ctx::TileScratch& sc, uint64_t nseg, uint64_t seg_len, const lrc_compact_io* io, hipStream_t st) {
+    const uint64_t tps = (seg_len + 63) / 64;
+    const uint64_t ntiles = nseg * tps;
+    const uint64_t nblocks = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+    // the trace kernel can hand over its per-wave keep counts (lrc_hits.tile_count) when tiles line up
+    const uint32_t* cnt = (io->tile_count && seg_len % 64 == 0) ? io->tile_count : nullptr;
+    if (!cnt) {
+        hipLaunchKernelGGL(compact_count_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, io->t, seg_len,
+                           tps, ntiles, sc.d_tile_cnt);
+        cnt = sc.d_tile_cnt;
+    }
+    const uint64_t nsuper = (ntiles + 1023) / 1024;
+    hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(64), 0, st, cnt, ntiles, (uint64_t)0,
+                       sc.d_tile_off, ntiles, sc.d_super_total);
+    // few super tiles (a C3 scan has 64): every scatter wave sums the totals in front of it itself, one launch less
+    const bool inline_bases = nsuper <= 512;
+    if (!inline_bases)
+        hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(64), 0, st, (const uint32_t*)sc.d_super_total,
+                           sc.d_super_base, nsuper);
+    // the scatter grid must also cover the threads that write the per-segment counts (one per segment)
+    const uint64_t need = io->counts ? (nseg + kBlock - 1) / kBlock : 0;
+    const uint64_t grid = nblocks > need ? nblocks : need;
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, st, *io, seg_len, tps,
+                       ntiles, nseg, (const uint32_t*)sc.d_tile_off, (const uint64_t*)sc.d_super_base, (uint64_t)0,
+                       inline_bases ? (const uint32_t*)sc.d_super_total : (const uint32_t*)nullptr);
+    LRC_HIP(hipGetLastError());
+    return LRC_OK;
+}
+
 
 int lrc_compact_dev(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_compact_io* io,
                     void* stream) {
@@ -2033,34 +2251,40 @@ int lrc_compact_dev(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_com
     const uint64_t ntiles = nseg * tps;
     const uint64_t nblocks = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
     if (nblocks > 0x7FFFFFFFull) return fail(LRC_ERR_INVALID_ARG, "lrc_compact_dev: too many entries");
-    lrc_ctx::TileScratch& sc = ctx->compact_scratch;
+    int set = -1;
     {
-        int rc_scratch = ensure_tile_scratch(ctx, sc, ntiles);
+        int rc_scratch = compact_scratch_for(ctx, st, ntiles, &set);
         if (rc_scratch) return rc_scratch;
     }
-    // the trace kernel can hand over its per-wave keep counts (lrc_hits.tile_count) when tiles line up
-    const uint32_t* cnt = (io->tile_count && seg_len % 64 == 0) ? io->tile_count : nullptr;
-    if (!cnt) {
-        hipLaunchKernelGGL(compact_count_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, io->t, seg_len,
-                           tps, ntiles, sc.d_tile_cnt);
-        cnt = sc.d_tile_cnt;
+    {
+        int rc_enq = enqueue_compaction(ctx->compact_scratch[set], nseg, seg_len, io, st);
+        if (rc_enq) return rc_enq;
     }
-    const uint64_t nsuper = (ntiles + 1023) / 1024;
-    hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(1024), 0, st, cnt, ntiles, (uint64_t)0,
-                       sc.d_tile_off, ntiles, sc.d_super_total);
-    // few super tiles (a C3 scan has 64): every scatter wave sums the totals in front of it itself, one launch less
-    const bool inline_bases = nsuper <= 512;
-    if (!inline_bases)
-        hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)sc.d_super_total,
-                           sc.d_super_base, nsuper);
-    // the scatter grid must also cover the threads that write the per-segment counts (one per segment)
-    const uint64_t need = io->counts ? (nseg + kBlock - 1) / kBlock : 0;
-    const uint64_t grid = nblocks > need ? nblocks : need;
-    hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, st, *io, seg_len, tps,
-                       ntiles, nseg, (const uint32_t*)sc.d_tile_off, (const uint64_t*)sc.d_super_base, (uint64_t)0,
-                       inline_bases ? (const uint32_t*)sc.d_super_total : (const uint32_t*)nullptr);
-    LRC_HIP(hipGetLastError());
+    LRC_HIP(hipEventRecord(ctx->compact_done[set], st));
     return LRC_OK;
+}
+
+// The scratch set of a compaction on stream `st`: the one that stream used last; otherwise the next set in turn, ordered
+// behind whatever another stream may still be doing with it (an event wait; free when that work is long done).
+static int compact_scratch_for(lrc_ctx* ctx, hipStream_t st, uint64_t ntiles, int* out_set) {
+    int set = -1;
+    for (int k = 0; k < lrc_ctx::kCompactSets; ++k)
+        if (ctx->compact_used[k] && ctx->compact_stream[k] == st) { set = k; break; }
+    if (set < 0) {
+        set = ctx->compact_next;
+        ctx->compact_next = (ctx->compact_next + 1) % lrc_ctx::kCompactSets;
+        if (!ctx->compact_done[set]) LRC_HIP(hipEventCreateWithFlags(&ctx->compact_done[set], hipEventDisableTiming));
+        else if (ctx->compact_used[set]) LRC_HIP(hipStreamWaitEvent(st, ctx->compact_done[set], 0));
+        ctx->compact_stream[set] = st;
+        ctx->compact_used[set] = true;
+    }
+    lrc_ctx::TileScratch& sc = ctx->compact_scratch[set];
+    if (sc.tile_cap < ntiles + 1 && sc.d_tile_off) {
+        // growing frees the old arrays: whatever still reads them must be done first
+        LRC_HIP(hipEventSynchronize(ctx->compact_done[set]));
+    }
+    *out_set = set;
+    return ensure_tile_scratch(ctx, sc, ntiles);
 }
 
 static int ensure_tile_scratch(lrc_ctx* ctx, lrc_ctx::TileScratch& sc, uint64_t ntiles) {
@@ -2076,6 +2300,232 @@ static int ensure_tile_scratch(lrc_ctx* ctx, lrc_ctx::TileScratch& sc, uint64_t 
     LRC_HIP(hipMalloc((void**)&sc.d_super_total, ((ntiles + 1023) / 1024 + 1) * 4));
     LRC_HIP(hipMalloc((void**)&sc.d_super_base, ((ntiles + 1023) / 1024 + 1) * 8));
     sc.tile_cap = ntiles + 1;
+    return LRC_OK;
+}
+
+// ---- the scan pipeline (include/lidarcast.h: lrc_pipe_*) ---------------------------------------------------------------------
+// Consecutive pose batches of one scene, scanned and compacted with the launches overlapped INSIDE the library.
+// What the measurements of round 4 say about this chip (DESIGN.md "the launch tail"; profiles/r04_chain_timeline_before.txt,
+// r04_queue_share.txt, r04_pipe_arrangements.txt):
+//   * a trace launch -- 65 536 one-wave workgroups that take a wave slot the moment it is freed -- keeps the dispatcher to
+//     itself while it has workgroups left: another stream's kernel gets a trickle of slots if its workgroups are one wave
+//     (a 32-workgroup kernel: 30-160 us) and none at all if they are 4 or 16 waves.  When the launch has handed out its
+//     last workgroup the next READY kernel of any stream takes over, into the slots the launch's long last waves leave
+//     empty (a 64-pose launch alone loses 50-60 us to that tail).
+//   * so two trace launches on two streams with NOTHING between two launches of a stream overlap perfectly (+12 %), and
+//     the moment a compaction sits between them (trace -> scan -> scatter -> trace per stream) it waits for the OTHER
+//     stream's whole dispatch phase, the trace behind it waits too, and the two chains run in lock step (+0...6 %).
+// Hence: trace launches of consecutive submits alternate between two streams; the 32-workgroup scan pass of submit k sits
+// behind its trace (it trickles in during the other stream's launch, nothing waits for it); and the scatter of submit k is not
+// a launch at all: it rides at the FRONT of the trace launch of submit k+2 (same stream, TraceParams::pre: one tile per
+// one-wave workgroup), so it is handed out exactly when the previous launch's tail begins and is gone in microseconds.  Four
+// record sets: set k is read by launch k+2 and written again by launch k+4, both on its own stream.
+struct lrc_pipe {
+    lrc_scene* scene = nullptr;
+    uint64_t max_poses = 0, rays_per_pose = 0, cap = 0;      // cap = max_poses * rays_per_pose records per set
+    static constexpr int kSets = 4;
+    void* slab[kSets] = {};                                  // one allocation per record set
+    lrc_hits rec[kSets] = {};
+    lrc_compact_io out[kSets] = {};                          // the caller's output buffers of the submit that used the set
+    uint64_t poses[kSets] = {};                              // its pose count
+    bool pending[kSets] = {};                                // scanned, scan pass enqueued, rows not yet scattered
+    lrc_ctx::TileScratch scratch[2];                         // per trace stream: offsets of the scan waiting for its scatter
+    hipStream_t s_trace[2] = {};
+    hipEvent_t ev_in[kSets] = {}, ev_t0[kSets] = {}, ev_trace[kSets] = {}, ev_flush[2] = {};
+    bool fused = true;                                       // false: N % 64 != 0 or > 512 super tiles: plain chain per stream
+    uint64_t ticket = 0;                                     // submits so far; submit k uses set k % 4, trace stream k % 2
+};
+
+int lrc_pipe_destroy(lrc_pipe* pp) {
+    if (!pp) return LRC_OK;
+    if (pp->scene && pp->scene->ctx) (void)hipSetDevice(pp->scene->ctx->device);
+    for (hipStream_t st : {pp->s_trace[0], pp->s_trace[1]})
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (int k = 0; k < lrc_pipe::kSets; ++k) {
+        if (pp->slab[k]) (void)hipFree(pp->slab[k]);
+        for (hipEvent_t e : {pp->ev_in[k], pp->ev_t0[k], pp->ev_trace[k]}) if (e) (void)hipEventDestroy(e);
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (pp->ev_flush[k]) (void)hipEventDestroy(pp->ev_flush[k]);
+        lrc_ctx::TileScratch& sc = pp->scratch[k];
+        if (sc.d_tile_off) (void)hipFree(sc.d_tile_off);
+        if (sc.d_tile_cnt) (void)hipFree(sc.d_tile_cnt);
+        if (sc.d_super_total) (void)hipFree(sc.d_super_total);
+        if (sc.d_super_base) (void)hipFree(sc.d_super_base);
+    }
+    delete pp;
+    return LRC_OK;
+}
+
+int lrc_pipe_create(lrc_scene* s, uint64_t max_poses, uint64_t rays_per_pose, lrc_pipe** out_pipe) {
+    if (!out_pipe) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_create: out_pipe is NULL");
+    *out_pipe = nullptr;
+    if (!s) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_create: scene is NULL");
+    if (max_poses == 0 || rays_per_pose == 0) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_create: max_poses and rays_per_pose must be positive");
+    if (max_poses > 0x7FFFFFFFull || max_poses * rays_per_pose / rays_per_pose != max_poses || max_poses * rays_per_pose > (1ull << 36))
+        return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_create: batch too large");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    lrc_pipe* pp = new (std::nothrow) lrc_pipe();
+    if (!pp) return fail(LRC_ERR_OOM, "lrc_pipe_create: out of host memory");
+    pp->scene = s;
+    pp->max_poses = max_poses;
+    pp->rays_per_pose = rays_per_pose;
+    const uint64_t n = pp->cap = max_poses * rays_per_pose;
+    const uint64_t tiles = max_poses * ((rays_per_pose + 63) / 64);
+    pp->fused = rays_per_pose % 64 == 0 && (tiles + 1023) / 1024 <= 512;
+    auto bail = [&](int rc) { (void)lrc_pipe_destroy(pp); return rc; };
+    auto up = [](uint64_t b) { return (b + 255) & ~255ull; };
+    // a record set: t | prim | normal3 | point3 | sem | ins | tile_count, 36 B per ray + 4 B per 64 rays
+    const uint64_t off_t = 0, off_prim = off_t + up(4 * n), off_nrm = off_prim + up(4 * n), off_pt = off_nrm + up(12 * n),
+                   off_sem = off_pt + up(12 * n), off_ins = off_sem + up(2 * n), off_tc = off_ins + up(2 * n),
+                   bytes = off_tc + up(4 * ((n + 63) / 64));
+    for (int k = 0; k < lrc_pipe::kSets; ++k) {
+        hipError_t e = hipMalloc(&pp->slab[k], bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); return bail(fail(LRC_ERR_OOM, "lrc_pipe_create: out of device memory for the record sets")); }
+        char* b = (char*)pp->slab[k];
+        lrc_hits& h = pp->rec[k];
+        h.t = (float*)(b + off_t); h.prim = (uint32_t*)(b + off_prim); h.normal3 = (float*)(b + off_nrm);
+        h.point3 = (float*)(b + off_pt); h.sem = (uint16_t*)(b + off_sem); h.ins = (uint16_t*)(b + off_ins);
+        h.tile_count = (uint32_t*)(b + off_tc);
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (hipStreamCreateWithFlags(&pp->s_trace[k], hipStreamNonBlocking) != hipSuccess) return bail(fail(LRC_ERR_HIP, "lrc_pipe_create: stream"));
+        if (hipEventCreateWithFlags(&pp->ev_flush[k], hipEventDisableTiming) != hipSuccess) return bail(fail(LRC_ERR_HIP, "lrc_pipe_create: event"));
+        int rc = ensure_tile_scratch(s->ctx, pp->scratch[k], tiles);
+        if (rc) return bail(rc);
+    }
+    for (int k = 0; k < lrc_pipe::kSets; ++k) {
+        if (hipEventCreateWithFlags(&pp->ev_in[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreate(&pp->ev_t0[k]) != hipSuccess || hipEventCreate(&pp->ev_trace[k]) != hipSuccess)
+            return bail(fail(LRC_ERR_HIP, "lrc_pipe_create: event"));
+    }
+    *out_pipe = pp;
+    return LRC_OK;
+}
+
+namespace {
+// the compaction input of the records in set `set`
+lrc_compact_io pipe_io(const lrc_pipe* pp, int set) {
+    lrc_compact_io io = pp->out[set];
+    const lrc_hits& h = pp->rec[set];
+    io.t = h.t; io.point3 = h.point3; io.sem = h.sem; io.ins = h.ins; io.incident_deg = nullptr; io.tile_count = h.tile_count;
+    return io;
+}
+}  // namespace
+
+int lrc_pipe_submit(lrc_pipe* pp, const double* d_poses16, uint64_t P, const double* d_dirs3, double max_range,
+                    const lrc_compact_io* d_out, void* stream, uint64_t* out_ticket) {
+    if (!pp || !d_out) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_submit: NULL pipe or output");
+    if (P == 0) { if (out_ticket) *out_ticket = pp->ticket; return LRC_OK; }
+    if (P > pp->max_poses) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_submit: more poses than the pipeline was created for");
+    if (!d_poses16 || !d_dirs3) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_submit: poses16 or dirs3 is NULL");
+    if (d_out->out_incident_deg) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_submit: the pipeline's records carry no incident angle");
+    lrc_scene* s = pp->scene;
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    const uint64_t k = pp->ticket;
+    const int set = (int)(k % lrc_pipe::kSets), lane = (int)(k % 2);
+    hipStream_t T = pp->s_trace[lane];
+    // inputs (poses, table) and outputs (the caller's rows and counts) are the caller's as of this point of its stream
+    LRC_HIP(hipEventRecord(pp->ev_in[set], (hipStream_t)stream));
+    LRC_HIP(hipStreamWaitEvent(T, pp->ev_in[set], 0));
+    const uint64_t N = pp->rays_per_pose;
+    TraceParams p{};
+    p.poses16 = d_poses16;
+    p.dirs3 = d_dirs3;
+    p.rays_per_pose = N;
+    p.total = P * N;
+    p.has_center = 1;
+    p.max_range = max_range;
+    p.out = pp->rec[set];
+    // the rows of submit k - 2 (this stream's previous scan; its scan pass was enqueued behind its trace) ride in front
+    const int prev = (int)((k + lrc_pipe::kSets - 2) % lrc_pipe::kSets);
+    lrc_compact_io pio{};
+    if (pp->fused && k >= 2 && pp->pending[prev]) {
+        pio = pipe_io(pp, prev);
+        const uint64_t tps = N / 64, ntiles = pp->poses[prev] * tps;
+        const uint64_t need = pio.counts ? (pp->poses[prev] + kTBlock - 1) / kTBlock : 0;
+        const uint64_t tile_blocks = (ntiles + kPreTiles - 1) / kPreTiles;
+        p.pre.blocks = (uint32_t)(tile_blocks > need ? tile_blocks : need);
+        p.pre.rows_only = (pio.out_xyzl && !pio.out_point3 && !pio.out_sem && !pio.out_ins && !pio.out_index && !pio.out_range_origin) ? 1u : 0u;
+        p.pre.seg_len = N; p.pre.tps = tps; p.pre.ntiles = ntiles; p.pre.nseg = pp->poses[prev];
+        p.pre.tile_off = pp->scratch[lane].d_tile_off;
+        p.pre.super_total = pp->scratch[lane].d_super_total;
+        p.pre.io = pio;
+    }
+    LRC_HIP(hipEventRecord(pp->ev_t0[set], T));
+    int rc = launch_trace(s, p, 1, T);
+    if (rc) return rc;
+    LRC_HIP(hipEventRecord(pp->ev_trace[set], T));
+    if (p.pre.blocks) pp->pending[prev] = false;
+    pp->out[set] = *d_out;
+    pp->poses[set] = P;
+    if (pp->fused) {
+        // the scan pass over this scan's per-wave keep counts: 32-64 one-wave workgroups behind the trace; the rows follow
+        // with this stream's next launch (or with lrc_pipe_wait)
+        const uint64_t ntiles = P * (N / 64), nsuper = (ntiles + 1023) / 1024;
+        // FOUR waves: beside the other stream's running launch a kernel of this stream is handed a wave slot every few
+        // microseconds at best; 64 one-wave workgroups took 300 us to arrive (the next launch of this stream behind them), four
+        // are in within 20 us and done long before that launch has handed out its last workgroup
+#ifndef LRC_PIPE_SCAN_WAVES
+#define LRC_PIPE_SCAN_WAVES 4
+#endif
+        hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)(nsuper < LRC_PIPE_SCAN_WAVES ? nsuper : LRC_PIPE_SCAN_WAVES)), dim3(64), 0, T, (const uint32_t*)pp->rec[set].tile_count,
+                           ntiles, (uint64_t)0, pp->scratch[lane].d_tile_off, ntiles, pp->scratch[lane].d_super_total);
+        LRC_HIP(hipGetLastError());
+        pp->pending[set] = true;
+    } else {
+        lrc_compact_io io = pipe_io(pp, set);
+        rc = enqueue_compaction(pp->scratch[lane], P, N, &io, T);
+        if (rc) return rc;
+    }
+    pp->ticket = k + 1;
+    if (out_ticket) *out_ticket = k + 1;
+    return LRC_OK;
+}
+
+int lrc_pipe_wait(lrc_pipe* pp, void* stream) {
+    if (!pp) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_wait: pipe is NULL");
+    if (pp->ticket == 0) return LRC_OK;
+    LRC_HIP(hipSetDevice(pp->scene->ctx->device));
+    // the rows still waiting for a launch to ride on (the last two submits) are scattered by the plain kernel
+    for (uint64_t back = 2; back >= 1; --back) {
+        if (pp->ticket < back) continue;
+        const uint64_t k = pp->ticket - back;
+        const int set = (int)(k % lrc_pipe::kSets), lane = (int)(k % 2);
+        if (!pp->pending[set]) continue;
+        lrc_compact_io io = pipe_io(pp, set);
+        const uint64_t N = pp->rays_per_pose, tps = N / 64, ntiles = pp->poses[set] * tps;
+        const uint64_t nblocks = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+        const uint64_t need = io.counts ? (pp->poses[set] + kBlock - 1) / kBlock : 0;
+        hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)(nblocks > need ? nblocks : need)), dim3(kBlock), 0, pp->s_trace[lane],
+                           io, N, tps, ntiles, pp->poses[set], (const uint32_t*)pp->scratch[lane].d_tile_off,
+                           (const uint64_t*)nullptr, (uint64_t)0, (const uint32_t*)pp->scratch[lane].d_super_total);
+        LRC_HIP(hipGetLastError());
+        pp->pending[set] = false;
+    }
+    for (int lane = 0; lane < 2; ++lane) {
+        LRC_HIP(hipEventRecord(pp->ev_flush[lane], pp->s_trace[lane]));
+        LRC_HIP(hipStreamWaitEvent((hipStream_t)stream, pp->ev_flush[lane], 0));
+    }
+    return LRC_OK;
+}
+
+int lrc_pipe_records(lrc_pipe* pp, uint64_t ticket, lrc_hits* out_records) {
+    if (!pp || !out_records) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_records: NULL argument");
+    if (ticket == 0 || ticket > pp->ticket || pp->ticket - ticket >= (uint64_t)lrc_pipe::kSets)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_records: the records of that submit are gone (four sets rotate)");
+    *out_records = pp->rec[(ticket - 1) % lrc_pipe::kSets];
+    return LRC_OK;
+}
+
+int lrc_pipe_trace_ms(lrc_pipe* pp, uint64_t ticket, float* out_ms) {
+    if (!pp || !out_ms) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_trace_ms: NULL argument");
+    if (ticket == 0 || ticket > pp->ticket || pp->ticket - ticket >= (uint64_t)lrc_pipe::kSets)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_trace_ms: the events of that submit have been reused");
+    const int set = (int)((ticket - 1) % lrc_pipe::kSets);
+    LRC_HIP(hipSetDevice(pp->scene->ctx->device));
+    LRC_HIP(hipEventSynchronize(pp->ev_trace[set]));
+    LRC_HIP(hipEventElapsedTime(out_ms, pp->ev_t0[set], pp->ev_trace[set]));
     return LRC_OK;
 }
 
@@ -2097,9 +2547,9 @@ int lrc_cloud_from_ranges_dev(lrc_ctx* ctx, const double* d_poses16, uint64_t P,
     const uint64_t nsuper = (ntiles + 1023) / 1024;
     hipLaunchKernelGGL(cloud_count_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, (const uint2*)d_t_label, N,
                        tps, ntiles, sc.d_tile_cnt);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(1024), 0, st,
+    hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(64), 0, st,
                        (const uint32_t*)sc.d_tile_cnt, ntiles, (uint64_t)0, sc.d_tile_off, ntiles, sc.d_super_total);
-    hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)sc.d_super_total,
+    hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(64), 0, st, (const uint32_t*)sc.d_super_total,
                        sc.d_super_base, nsuper);
     const uint64_t need = d_counts ? (P + kBlock - 1) / kBlock : 0;
     const uint64_t grid = nblocks > need ? nblocks : need;
@@ -2142,17 +2592,17 @@ static int prepare_rebuild(lrc_scene* s, const char* who, const double* d_poses1
     const uint64_t nsuper = (ntiles + 1023) / 1024;
     if (d_tile_count) {
         // the senders' trace kernels already counted (lrc_hits.tile_count travels in the slab): no counting pass
-        hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(1024), 0, st, d_tile_count,
+        hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(64), 0, st, d_tile_count,
                            poses_per_slab * tps, stride, sc.d_tile_off, ntiles, sc.d_super_total);
     } else {
         const uint64_t nblocks = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
         hipLaunchKernelGGL(prim_count_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, d_prim, poses_per_slab,
                            stride, N, tps, ntiles, sc.d_tile_cnt);
-        hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(1024), 0, st,
+        hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)nsuper), dim3(64), 0, st,
                            (const uint32_t*)sc.d_tile_cnt, ntiles, (uint64_t)0, sc.d_tile_off, ntiles,
                            sc.d_super_total);
     }
-    hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)sc.d_super_total,
+    hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(64), 0, st, (const uint32_t*)sc.d_super_total,
                        sc.d_super_base, nsuper);
     hipLaunchKernelGGL(dirs_transpose_kernel, dim3((uint32_t)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                        d_dirs3, (uint32_t)N, sc.d_dirs_soa);
@@ -2299,8 +2749,8 @@ int lrc_compact(lrc_ctx* ctx, uint64_t nseg, uint64_t seg_len, const lrc_compact
 
 // ---- scan straight to the reference's variable-length frames ----------------------------------------------------
 namespace {
-// The *_compact entry points enqueue their input copies on the null stream before anything can fail: an error return
-// must not leave such a copy in flight over staging buffers the next call reuses.
+// The *_compact entry points enqueue their input copies (on the context's compute stream, which consumes them) before
+// anything can fail: an error return must not leave such a copy in flight over staging buffers the next call reuses.
 struct SyncUnlessOk {
     bool armed = true;
     ~SyncUnlessOk() { if (armed) (void)hipDeviceSynchronize(); }

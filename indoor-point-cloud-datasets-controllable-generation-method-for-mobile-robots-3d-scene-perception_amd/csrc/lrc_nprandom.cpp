@@ -31,6 +31,7 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -39,6 +40,43 @@
 extern "C" int lrc_internal_fail(int code, const char* msg);
 
 namespace {
+
+// Thread starts can fail (EAGAIN at a pid / thread limit -> std::system_error).  Every start goes through try_start(): a
+// failed start returns false and leaves the vector as it was, so that the caller can go on with fewer threads -- never an
+// exception that unwinds past joinable threads (std::terminate).  g_thread_budget >= 0 is a test hook
+// (lrc_internal_set_thread_budget): that many further starts succeed, the next ones fail as the system would make them.
+std::atomic<long> g_thread_budget{-1};
+
+template <class F>
+bool try_start(std::vector<std::thread>& pool, F&& f) {
+    long b = g_thread_budget.load();
+    while (b >= 0) {
+        if (b == 0) return false;
+        if (g_thread_budget.compare_exchange_weak(b, b - 1)) break;
+    }
+    try {
+        pool.emplace_back(std::forward<F>(f));
+        return true;
+    } catch (const std::system_error&) {
+        return false;
+    } catch (const std::bad_alloc&) {
+        return false;
+    }
+}
+
+// joins on every exit: `wind_down` makes the threads return (called first), then they are joined
+template <class W>
+struct JoinGuard {
+    std::vector<std::thread>& pool;
+    W wind_down;
+    ~JoinGuard() {
+        wind_down();
+        for (auto& t : pool) if (t.joinable()) t.join();
+    }
+};
+template <class W> JoinGuard<W> make_join_guard(std::vector<std::thread>& pool, W w) { return JoinGuard<W>{pool, std::move(w)}; }
+
+struct NoGeneratorThread {};      // the streaming path could not start its generator thread: take the sequential path
 
 constexpr int kN = 624, kM = 397;
 constexpr uint32_t kMatrixA = 0x9908b0dfu, kUpper = 0x80000000u, kLower = 0x7fffffffu;
@@ -441,9 +479,23 @@ int scan_streaming(lrc_mt19937_state* st, uint64_t num_poses, uint64_t normals_p
     S.P = num_poses; S.nn = normals_per_pose; S.nu = uniforms_per_pose;
     S.loc = loc; S.scale = scale; S.out_norm = out_normals; S.out_unif = out_uniforms;
     S.jobs.resize((size_t)num_poses);
-    std::thread gen(generate, &S, (const uint32_t*)st->key, st->pos);
-    std::vector<std::thread> pool;
-    for (int t = 2; t < nthreads; ++t) pool.emplace_back([&S] { S.worker(); });
+    // threads[0] = the generator, the rest = workers.  A start that fails leaves fewer workers (the walk helps with their
+    // tasks anyway); without the generator there is no streaming path.  The guard winds everything down and joins on every
+    // exit, exceptions included.
+    std::vector<std::thread> threads;
+    threads.reserve((size_t)std::max(nthreads, 2));
+    auto guard = make_join_guard(threads, [&S] {
+        S.stop.store(true, std::memory_order_release);
+        { std::lock_guard<std::mutex> l(S.qm); S.closed = true; S.tasks.clear(); }
+        S.qcv.notify_all();
+    });
+    {
+        const uint32_t* key0 = (const uint32_t*)st->key;
+        const int pos0 = st->pos;
+        if (!try_start(threads, [&S, key0, pos0] { generate(&S, key0, pos0); })) throw NoGeneratorThread{};
+    }
+    for (int t = 2; t < nthreads; ++t)
+        if (!try_start(threads, [&S] { S.worker(); })) break;
     // the walk: wait for chunk c's flags (helping with tasks meanwhile)
     auto flagged = [&](size_t c) -> Chunk* {
         for (;;) {
@@ -495,11 +547,8 @@ int scan_streaming(lrc_mt19937_state* st, uint64_t num_poses, uint64_t normals_p
         if (!S.help()) S.wait_until([&] { return S.poses_done.load() >= num_poses; });
     }
     } catch (...) { bad = true; }
-    S.stop.store(true, std::memory_order_release);
-    { std::lock_guard<std::mutex> l(S.qm); S.closed = true; S.tasks.clear(); }
-    S.qcv.notify_all();
-    gen.join();
-    for (auto& t : pool) t.join();
+    guard.wind_down();
+    for (auto& t : threads) t.join();
     if (bad || S.failed.load()) throw std::bad_alloc();
     // the generator state numpy would be left with: key = numpy's block of the last word consumed, pos = one past it.  numpy's
     // block b holds the words [624 b - pos0, 624 (b + 1) - pos0) of this call's stream; block 0 is the caller's key.
@@ -544,8 +593,10 @@ static int scan_sequential(lrc_mt19937_state* st, uint64_t num_poses, uint64_t n
         if ((uint64_t)nthreads > num_poses) nthreads = (int)num_poses;
         Queue queue;
         std::vector<std::thread> pool;
+        pool.reserve((size_t)nthreads);
+        auto guard = make_join_guard(pool, [&queue] { queue.finish(); });      // joins on every exit, exceptions included
         for (int t = 1; t < nthreads; ++t)
-            pool.emplace_back([&queue] { while (auto j = queue.pop()) run_job(*j); });
+            if (!try_start(pool, [&queue] { while (auto j = queue.pop()) run_job(*j); })) break;    // fewer threads, or none
         std::vector<uint32_t> flags;
         for (uint64_t p = 0; p < num_poses; ++p) {
             auto job = std::make_unique<PoseJob>();
@@ -617,7 +668,7 @@ static int scan_sequential(lrc_mt19937_state* st, uint64_t num_poses, uint64_t n
                 run_job(*j);
             }
             queue.finish();
-            for (auto& t : pool) t.join();
+            for (auto& t : pool) t.join();      // the transforms must be complete before the state is handed back
         }
         std::memcpy(st->key, s.key, sizeof(s.key));
         st->pos = s.pos;
@@ -630,6 +681,9 @@ static int scan_sequential(lrc_mt19937_state* st, uint64_t num_poses, uint64_t n
     }
     return LRC_OK;
 }
+
+// test hook (tests/test_nprandom.py): the next `budget` thread starts succeed, later ones fail like EAGAIN; < 0 = no limit
+extern "C" void lrc_internal_set_thread_budget(long budget) { g_thread_budget.store(budget); }
 
 extern "C" int lrc_rng_scan_draws(lrc_mt19937_state* st, uint64_t num_poses, uint64_t normals_per_pose,
                                   uint64_t uniforms_per_pose, double loc, double scale, double* out_normals,
@@ -650,6 +704,8 @@ extern "C" int lrc_rng_scan_draws(lrc_mt19937_state* st, uint64_t num_poses, uin
     if (threads >= 0 && aligned && nthreads >= 3 && shaped) {
         try {
             return scan_streaming(st, num_poses, normals_per_pose, uniforms_per_pose, loc, scale, out_normals, out_uniforms, nthreads);
+        } catch (const NoGeneratorThread&) {
+            // no thread could be started at all: nothing was consumed yet, the sequential path does the same draws
         } catch (const std::bad_alloc&) {
             return lrc_internal_fail(LRC_ERR_OOM, "lrc_rng_scan_draws: out of host memory");
         } catch (...) {

@@ -22,11 +22,12 @@ LRC_INVALID_PRIM = 0xFFFFFFFF
 # every symbol include/lidarcast.h declares (tests check that the library exports all of them)
 SYMBOLS = (
     "lrc_version", "lrc_last_error", "lrc_device_count",
-    "lrc_ctx_create", "lrc_ctx_destroy", "lrc_ctx_synchronize",
+    "lrc_ctx_create", "lrc_ctx_destroy", "lrc_ctx_synchronize", "lrc_ctx_set_launch_chaining", "lrc_ctx_get_launch_chaining",
     "lrc_scene_create", "lrc_scene_create_dev", "lrc_scene_destroy", "lrc_scene_get_info", "lrc_scene_export_bvh", "lrc_scene_export_array",
     "lrc_scene_get_counters", "lrc_scene_set_options", "lrc_scene_get_occupancy",
     "lrc_cast", "lrc_cast_dev", "lrc_cast_segments", "lrc_cast_segments_dev",
     "lrc_scan_poses", "lrc_scan_poses_dev", "lrc_scan_poses_compact", "lrc_host_alloc", "lrc_host_free",
+    "lrc_pipe_create", "lrc_pipe_destroy", "lrc_pipe_submit", "lrc_pipe_wait", "lrc_pipe_records", "lrc_pipe_trace_ms",
     "lrc_scan_angles_dev", "lrc_scan_angles_compact", "lrc_debug_scan_stats",
     "lrc_scan_grid_dev", "lrc_scan_grid_compact", "lrc_scan_rays_compact",
     "lrc_table_create", "lrc_table_destroy", "lrc_scan_table_compact",
@@ -112,6 +113,8 @@ def load():
         "lrc_ctx_create": [i32, C.POINTER(vp)],
         "lrc_ctx_destroy": [vp],
         "lrc_ctx_synchronize": [vp],
+        "lrc_ctx_set_launch_chaining": [vp, i32],
+        "lrc_ctx_get_launch_chaining": [vp, C.POINTER(i32), C.POINTER(i32)],
         "lrc_scene_create": [vp, vp, u64, vp, u64, vp, vp, C.POINTER(vp)],
         "lrc_scene_create_dev": [vp, vp, u64, vp, u64, vp, vp, C.POINTER(vp)],
         "lrc_scene_destroy": [vp],
@@ -128,6 +131,12 @@ def load():
         "lrc_scan_poses": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcHits)],
         "lrc_scan_poses_dev": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcHits), vp],
         "lrc_scan_poses_compact": [vp, vp, u64, vp, u64, dbl, C.POINTER(LrcFrames), u64, C.POINTER(u64)],
+        "lrc_pipe_create": [vp, u64, u64, C.POINTER(vp)],
+        "lrc_pipe_destroy": [vp],
+        "lrc_pipe_submit": [vp, vp, u64, vp, dbl, C.POINTER(LrcCompactIO), vp, C.POINTER(u64)],
+        "lrc_pipe_wait": [vp, vp],
+        "lrc_pipe_records": [vp, u64, C.POINTER(LrcHits)],
+        "lrc_pipe_trace_ms": [vp, u64, C.POINTER(C.c_float)],
         "lrc_host_alloc": [vp, u64, C.POINTER(vp)],
         "lrc_host_free": [vp, vp],
         "lrc_scan_angles_dev": [vp, vp, u64, vp, vp, u64, dbl, C.POINTER(LrcHits), vp],

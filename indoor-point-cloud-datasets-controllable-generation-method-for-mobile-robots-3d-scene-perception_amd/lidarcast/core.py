@@ -196,6 +196,16 @@ class Context:
     def synchronize(self):
         check(self._lib.lrc_ctx_synchronize(self._h), "lrc_ctx_synchronize")
 
+    def set_launch_chaining(self, enabled=True):
+        """Scans a caller keeps in flight on two streams start one behind the other's last workgroup (include/lidarcast.h)."""
+        check(self._lib.lrc_ctx_set_launch_chaining(self._h, 1 if enabled else 0), "lrc_ctx_set_launch_chaining")
+
+    def launch_chaining(self):
+        """(enabled, supported by this device)"""
+        e, s = C.c_int(0), C.c_int(0)
+        check(self._lib.lrc_ctx_get_launch_chaining(self._h, C.byref(e), C.byref(s)), "lrc_ctx_get_launch_chaining")
+        return bool(e.value), bool(s.value)
+
     def close(self):
         if getattr(self, "_h", None):
             self.pinned.clear()
@@ -684,6 +694,63 @@ class Scene:
             int(poses_per_slab), int(slab_stride_bytes), C.c_void_p(out_rows_t.data_ptr()),
             None if counts_t is None else C.c_void_p(counts_t.data_ptr()), C.c_void_p(int(stream))),
             "lrc_cloud_from_prims_dev")
+
+
+class ScanPipe:
+    """Consecutive pose batches of one scene, scanned and compacted with the launches overlapped inside the library
+    (lrc_pipe_*: the trace of batch k+1 fills the wave slots the trace of batch k leaves empty in its tail; the compaction
+    runs beside it at high stream priority).  Everything stays in HBM; `submit` only enqueues, `wait` orders a stream
+    behind all submits so far.  The poses of a trajectory are independent (reference: s3dis_simulator.py:254-288)."""
+
+    def __init__(self, scene, max_poses, rays_per_pose):
+        self._lib = _capi.load()
+        self.scene = scene
+        self.max_poses, self.rays_per_pose = int(max_poses), int(rays_per_pose)
+        h = C.c_void_p()
+        check(self._lib.lrc_pipe_create(scene._h, self.max_poses, self.rays_per_pose, C.byref(h)), "lrc_pipe_create")
+        self._h = h
+
+    def submit(self, poses_t, dirs_t, max_range, io=None, out_rows_t=None, counts_t=None, stream=0):
+        """io: LrcCompactIO whose out_* members / counts point at the caller's device buffers; or pass torch tensors
+        (out_rows_t: (K,4) float32 rows x, y, z, label bits; counts_t: (P,) int64).  Returns the submit's ticket."""
+        if dirs_t.shape[0] != self.rays_per_pose:
+            raise ValueError("direction table does not match the pipeline's rays_per_pose")
+        if io is None:
+            io = _capi.LrcCompactIO()
+            if out_rows_t is not None:
+                io.out_xyzl = out_rows_t.data_ptr()
+            if counts_t is not None:
+                io.counts = counts_t.data_ptr()
+        ticket = C.c_uint64(0)
+        check(self._lib.lrc_pipe_submit(self._h, C.c_void_p(poses_t.data_ptr()), poses_t.shape[0],
+                                        C.c_void_p(dirs_t.data_ptr()), float(max_range), C.byref(io),
+                                        C.c_void_p(int(stream)), C.byref(ticket)), "lrc_pipe_submit")
+        return ticket.value
+
+    def wait(self, stream=0):
+        check(self._lib.lrc_pipe_wait(self._h, C.c_void_p(int(stream))), "lrc_pipe_wait")
+
+    def records(self, ticket):
+        """LrcHits (device pointers) of the fixed-stride records of that submit; valid until two further submits."""
+        h = _capi.LrcHits()
+        check(self._lib.lrc_pipe_records(self._h, int(ticket), C.byref(h)), "lrc_pipe_records")
+        return h
+
+    def trace_ms(self, ticket):
+        ms = C.c_float(0.0)
+        check(self._lib.lrc_pipe_trace_ms(self._h, int(ticket), C.byref(ms)), "lrc_pipe_trace_ms")
+        return float(ms.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lrc_pipe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class NearestIndex:

@@ -172,3 +172,28 @@ def test_native_ray_composition_equals_the_numpy_formula():
     assert np.array_equal(ref.view(np.uint32), out.view(np.uint32))
     assert lib.lrc_rays_from_trig(None, None, None, None, 0, None, None) == 0
     assert lib.lrc_rays_from_trig(None, st.ctypes.data, cp.ctypes.data, sp.ctypes.data, n, M.ctypes.data, out.ctypes.data) != 0
+
+
+@pytest.mark.parametrize("budget", [0, 1, 2, 4])
+@pytest.mark.parametrize("threads", [8, -4])
+def test_thread_start_failures_leave_fewer_threads_not_a_dead_process(budget, threads):
+    """ADVICE r03: a std::thread that cannot start (EAGAIN at a thread limit) must not unwind past joinable threads
+    (std::terminate).  The hook makes the first `budget` starts succeed and every later one fail: no generator thread
+    -> the sequential path; some workers -> fewer workers; the draws and the state stay numpy's."""
+    import ctypes
+    import lidarcast
+    from lidarcast import nprandom
+    lib = lidarcast.load()
+    hook = lib.lrc_internal_set_thread_budget
+    hook.argtypes, hook.restype = [ctypes.c_long], None
+    P, nn, nu = 6, 20000, 10000
+    ref, mine = np.random.RandomState(21), np.random.RandomState(21)
+    zr, ur = _numpy_draws(ref, P, nn, nu, 0.0, 1e-3)
+    hook(budget)
+    try:
+        zm, um = nprandom.scan_draws(P, nn, nu, 0.0, 1e-3, rng=mine, threads=threads)
+    finally:
+        hook(-1)
+    assert np.array_equal(zr.view(np.uint64), zm.view(np.uint64))
+    assert np.array_equal(ur.view(np.uint64), um.view(np.uint64))
+    assert _same_state(ref.get_state(), mine.get_state())

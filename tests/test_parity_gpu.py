@@ -1250,3 +1250,111 @@ def test_export_labels_from_annotation_files(tmp_path, engine):
     assert np.array_equal(out["sem"], al[j].astype(np.uint16)) and np.array_equal(out["ins"], ai[j].astype(np.uint16))
     assert np.array_equal(np.stack([out["red"], out["green"], out["blue"]], 1), (col[j] * 255).astype(np.uint8))
 
+
+
+def test_scan_pipeline_equals_scan_plus_compaction(ctx):
+    """lrc_pipe_*: batches submitted back to back (trace launches alternating between two internal streams, the rows of
+    submit k scattered by the leading workgroups of the trace launch of submit k+2, four rotating record sets) against the
+    same batches through lrc_scan_poses_dev + lrc_compact_dev on one stream: rows, per-pose counts and the fixed-stride
+    records, bit for bit -- ragged batch sizes, every output kind, a flush in the middle, and the fallback for tables whose
+    tiles do not line up.  Poses are independent (reference: s3dis_simulator.py:254-288), so the order of execution is free."""
+    import ctypes as C
+    import torch
+    import lidarcast
+    from lidarcast import synth
+    from lidarcast._capi import LrcCompactIO
+    from lidar import IndoorLidar
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=4, seed=5, cell=0.04)
+    scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(3)
+    for lines, width, max_range, pmax in ((8, 512, 2.5, 9), (4, 256, 20.0, 33), (3, 100, 20.0, 6)):
+        k = sensor_small(lines=lines, width=width, max_range=max_range)
+        dirs = IndoorLidar(k, np.eye(4)).sensor_directions()
+        N = len(dirs)
+        d_dirs = torch.from_numpy(dirs).to(dev)
+        pipe = lidarcast.ScanPipe(scene, pmax, N)
+        hits = lidarcast.DeviceHits(pmax * N, dev, want=("t", "prim", "normal3", "point3", "sem", "ins", "tile_count"))
+        batches, outs = [], []
+        sizes = [pmax, 1, pmax - 2, 3, pmax, 2, pmax - 1, pmax]
+        for b, P in enumerate(sizes):
+            poses = np.stack([pose(0.6 + 2.8 * rng.random(), 0.6 + 1.8 * rng.random(), 0.5 + 1.5 * rng.random(),
+                                   yaw=rng.uniform(-3, 3)) for _ in range(P)])
+            d_poses = torch.from_numpy(poses.reshape(P, 16)).to(dev)
+            rows = torch.full((P * N, 4), -7.0, dtype=torch.float32, device=dev)
+            counts = torch.full((P,), -1, dtype=torch.int64, device=dev)
+            io = LrcCompactIO()
+            io.counts = counts.data_ptr()
+            extra = {}
+            if b % 3 == 1:            # every output kind: the per-tile form of the leading workgroups
+                extra = {"p3": torch.zeros((P * N, 3), dtype=torch.float32, device=dev),
+                         "sem": torch.zeros(P * N, dtype=torch.int16, device=dev),
+                         "ins": torch.zeros(P * N, dtype=torch.int16, device=dev),
+                         "idx": torch.zeros(P * N, dtype=torch.int32, device=dev),
+                         "rng": torch.zeros(P * N, dtype=torch.float32, device=dev)}
+                io.out_point3, io.out_sem, io.out_ins = extra["p3"].data_ptr(), extra["sem"].data_ptr(), extra["ins"].data_ptr()
+                io.out_index, io.out_range_origin = extra["idx"].data_ptr(), extra["rng"].data_ptr()
+                if b % 2:
+                    io.out_xyzl = rows.data_ptr()
+            else:
+                io.out_xyzl = rows.data_ptr()
+            ticket = pipe.submit(d_poses, d_dirs, k.max_range, io=io, stream=st)
+            batches.append((d_poses, P, ticket))
+            outs.append((rows, counts, extra, io))
+            if b == 4:                # a flush in the middle: everything so far is complete, the pipeline starts afresh
+                pipe.wait(st)
+                torch.cuda.synchronize()
+                assert all(int(o[1].min().item()) >= 0 for o in outs)
+        pipe.wait(st)
+        torch.cuda.synchronize()
+        # the records of the last submits are still there (four sets rotate)
+        for (d_poses, P, ticket), (rows, counts, extra, io) in zip(batches, outs):
+            rows2 = torch.full_like(rows, -7.0)
+            counts2 = torch.full_like(counts, -1)
+            io2 = LrcCompactIO()
+            io2.t, io2.point3, io2.sem, io2.ins = (hits[a].data_ptr() for a in ("t", "point3", "sem", "ins"))
+            io2.tile_count, io2.counts, io2.out_xyzl = hits["tile_count"].data_ptr(), counts2.data_ptr(), rows2.data_ptr()
+            extra2 = {n_: torch.zeros_like(t_) for n_, t_ in extra.items()}
+            if extra:
+                io2.out_point3, io2.out_sem, io2.out_ins = extra2["p3"].data_ptr(), extra2["sem"].data_ptr(), extra2["ins"].data_ptr()
+                io2.out_index, io2.out_range_origin = extra2["idx"].data_ptr(), extra2["rng"].data_ptr()
+            scene.scan_poses_dev(d_poses, d_dirs, hits, k.max_range, st)
+            ctx.compact_dev(P, N, io2, st)
+            torch.cuda.synchronize()
+            assert torch.equal(counts, counts2), f"per-pose counts differ, batch of {P} poses"
+            kk = int(counts2.sum().item())
+            if io.out_xyzl:
+                assert torch.equal(rows[:kk].view(torch.int32), rows2[:kk].view(torch.int32)), "rows differ"
+                assert bool((rows[kk:] == -7.0).all()), "rows beyond the kept ones were touched"
+            for n_ in extra:
+                a, b2 = extra[n_][:kk], extra2[n_][:kk]
+                assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a,
+                                   b2.view(torch.int32) if b2.dtype == torch.float32 else b2), n_
+            if pipe_ticket_alive(pipe, ticket):
+                rec = pipe.records(ticket)
+                for name, width_ in (("t", 4), ("prim", 4), ("normal3", 12), ("point3", 12), ("sem", 2), ("ins", 2)):
+                    nbytes = P * N * width_
+                    got = (C.c_char * nbytes).from_buffer_copy(_dev_bytes(getattr(rec, name), nbytes))
+                    ref = hits[name].view(torch.uint8).flatten()[:nbytes].cpu().numpy().tobytes()
+                    assert bytes(got) == ref, f"records differ: {name}"
+        pipe.close()
+
+
+def pipe_ticket_alive(pipe, ticket):
+    try:
+        pipe.records(ticket)
+        return True
+    except ValueError:
+        return False
+
+
+def _dev_bytes(ptr, nbytes):
+    """nbytes at device address ptr as host bytes (through a torch byte tensor filled by hipMemcpy)."""
+    import ctypes as C
+    import torch
+    buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(C.c_void_p(buf.data_ptr()), C.c_void_p(int(ptr)), nbytes, 3) == 0      # device to device
+    return buf.cpu().numpy().tobytes()

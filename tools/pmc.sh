@@ -8,7 +8,8 @@ TAG=${1:-pmc}
 PAT=${2:-trace_kernel}
 # PMC_SCENE=<scene> profiles bench.py --scene <scene>; the summary (pmc.json) is then meant for profiles/pmc_<scene>.json
 SCENE_ARGS=${PMC_SCENE:+--scene $PMC_SCENE}
-ARGS=${PMC_ARGS:---steps 3 --warmup 1 --no-cpu-baseline --no-caller-path $SCENE_ARGS}
+# a caller's PMC_ARGS keeps the scene too (it used to drop it silently: a summary filed under the wrong scene name)
+ARGS="${PMC_ARGS:---steps 3 --warmup 1 --no-cpu-baseline --no-caller-path} $SCENE_ARGS"
 export PMC_ARGS="$ARGS"
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG

@@ -6,6 +6,10 @@ One "step" = one pass of the hot path over the whole trajectory batch, inputs re
   traversal, hit write-back of t/prim/normal/point/sem/ins, range filter)  ->  stable compaction
   into the scene cloud (np.vstack order); for N > 1 instead: one RCCL all-gather of the hit triangle ids and the
   rebuild of the whole scene cloud on every GPU.
+At N = 1 the steps go through the library's scan pipeline (lrc_pipe_*: consecutive batches, the trace launch of step k+1
+fills the wave slots the launch of step k leaves empty in its tail, the rows of step k are scattered by the leading
+workgroups of the launch of step k+2; same bytes as the two calls one after the other, checked in the run);
+--serial times the two calls on one stream instead (the round-3 step; what the rocprofv3 / PMC passes profile).
 Weak scaling: every rank scans its own 64 poses of a 64*N-pose trajectory over a replica of the scene.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the trace kernel against the roof that binds it -- vector-ALU issue
@@ -40,7 +44,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # VALU instruction issues over 2 cycles on a SIMD-32).  One lane-operation = one lane of one VALU instruction.
 VALU_PEAK_GLANEOPS = 256 * 4 * 32 * 2.4          # = 78 643.2 G lane-op/s
 N_SIMDS, CLOCK_GHZ = 1024, 2.4
-MIN_TIMED_SECONDS = 0.25     # the timed block of --steps steps is repeated until this much wall time has passed
+MIN_TIMED_SECONDS = 3.0      # the timed block of --steps steps is repeated until this much wall time has passed (the driver's
+                             # GPU-busy sampler must be able to see the device busy: round 3's 0.25 s fell between its samples)
 SCENE = "synth_A6_office2"
 POSES_PER_GPU = 64
 
@@ -128,13 +133,80 @@ def cpu_baseline(mesh, sensor, poses, budget_s=18.0):
         np_oracle.lidar_intersect_mesh(om, create_lidar(sensor, poses[done_once]), threads=threads)
         done_once += 1
     t_once = time.perf_counter() - t0
+    ref = open3d_leg(mesh, sensor, poses, budget_s * 0.5)
+    if ref is not None:
+        # Open3D is installed on this host: the reference's own CPU path (Embree through RaycastingScene) is the baseline,
+        # the port's figures ride along
+        ref.update({"port_value": done * n_per / t_faithful, "port_build_once_value": done_once * n_per / t_once,
+                    "port_cores": threads})
+        return ref
     return {
+        "open3d": "not installed on this host (import open3d: ModuleNotFoundError) -- the reference's Embree path cannot be "
+                  "timed; the figures below are the C restatement",
         "value": done * n_per / t_faithful, "unit": "rays/s", "cores": threads, "kind": "port",
         "sample": f"{done} of {len(poses)} poses x {n_per} rays of the C3 workload ({t_faithful:.1f} s of CPU work), "
                   f"scene (BVH) rebuilt per pose as the reference does; oracle/lrc_oracle.c (C, pthreads) + "
                   f"numpy ray generation and post-processing",
         "build_once_value": done_once * n_per / t_once,
         "build_once_sample": f"{done_once} poses in {t_once:.1f} s, BVH built once",
+    }
+
+
+def open3d_leg(mesh, sensor, poses, budget_s):
+    """The reference's CPU path itself, when Open3D is installed on the measuring host (SURVEY
+    section 8(d)): the sequence raycast_engine_cpu.py:46-73,95-107 runs per waypoint -- RaycastingScene() + from_legacy +
+    add_triangles (the Embree build, repeated per pose as the reference repeats it), cast_rays, the numpy post-processing --
+    written here against Open3D's public API (the reference's files do not travel to the GPU box), with this package's ray
+    generator.  Returns None when Open3D is absent (it is on the pool's boxes: probed in round 4)."""
+    try:
+        import open3d as o3d
+    except Exception:                                                    # noqa: BLE001 - absent or broken: no reference leg
+        return None
+    from lidar import create_lidar
+    legacy = o3d.geometry.TriangleMesh(o3d.utility.Vector3dVector(np.asarray(mesh.vertices, dtype=np.float64)),
+                                       o3d.utility.Vector3iVector(np.asarray(mesh.triangles, dtype=np.int32)))
+    n_per = sensor.vertical_res * sensor.horizontal_res
+
+    def one_pose(pose_m, scene_=None):
+        lidar = create_lidar(sensor, pose_m)
+        rays = lidar.get_rays()
+        sc = scene_
+        if sc is None:                                                   # raycast_engine_cpu.py:46-47
+            sc = o3d.t.geometry.RaycastingScene()
+            sc.add_triangles(o3d.t.geometry.TriangleMesh.from_legacy(legacy))
+        ans = sc.cast_rays(o3d.core.Tensor(rays.astype(np.float32)))     # :50-51
+        t = ans["t_hit"].numpy()
+        hit = t != np.inf                                                # :54-73
+        o, d = rays[hit, :3], rays[hit, 3:]
+        pts = o + d / np.linalg.norm(d, axis=1, keepdims=True) * t[hit][:, None]
+        c = lidar.pose[:3, 3]                                            # :95-107
+        dist_ = np.linalg.norm(pts - c, axis=1)
+        keep = dist_ < lidar.intrinsics.max_range
+        pts = pts[keep]
+        v = (pts - c) / np.linalg.norm(pts - c, axis=1, keepdims=True)
+        return pts, np.degrees(np.arccos(np.abs(v[:, 2])))
+
+    t_start, done, t_faithful = time.perf_counter(), 0, 0.0
+    while done < len(poses) and time.perf_counter() - t_start < budget_s * 0.65:
+        t0 = time.perf_counter()
+        one_pose(poses[done])
+        t_faithful += time.perf_counter() - t0
+        done += 1
+    sc = o3d.t.geometry.RaycastingScene()
+    sc.add_triangles(o3d.t.geometry.TriangleMesh.from_legacy(legacy))
+    t0, done_once = time.perf_counter(), 0
+    while done_once < len(poses) and time.perf_counter() - t0 < budget_s * 0.3:
+        one_pose(poses[done_once], sc)
+        done_once += 1
+    t_once = time.perf_counter() - t0
+    return {
+        "value": done * n_per / t_faithful, "unit": "rays/s", "cores": host_threads(), "kind": "reference",
+        "open3d": o3d.__version__,
+        "sample": f"{done} of {len(poses)} poses x {n_per} rays of the C3 workload ({t_faithful:.1f} s of CPU work): Open3D "
+                  f"{o3d.__version__} RaycastingScene rebuilt per pose + cast_rays + the numpy post-processing of "
+                  f"raycast_engine_cpu.py:54-107, all cores (Embree / TBB default)",
+        "build_once_value": done_once * n_per / t_once,
+        "build_once_sample": f"{done_once} poses in {t_once:.1f} s, RaycastingScene built once",
     }
 
 
@@ -186,6 +258,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-caller-path", action="store_true", help="skip the host-caller timing (N = 1 only)")
     ap.add_argument("--scene", default=SCENE)
+    ap.add_argument("--mesh", default=None, metavar="PLY",
+                    help="scan this triangle mesh (e.g. an NKSR mesh_dense.ply, as s3dis_simulator.py:556-591 prefers) instead of "
+                         "the procedural stand-in; read by the package's own PLY reader; the C3 poses are laid through the "
+                         "middle of its bounding box")
+    ap.add_argument("--serial", action="store_true",
+                    help="N = 1: time lrc_scan_poses_dev + lrc_compact_dev on one stream (the round-3 step) instead of the "
+                         "scan pipeline; what the rocprofv3 --stats / PMC passes profile (one un-overlapped trace launch per step)")
+    ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_SECONDS,
+                    help="repeat the timed block of --steps steps until this much wall time has passed")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="run the N>1 code path (RCCL all-gather, double buffering) with world size 1 and check "
                          "the assembled cloud against the local one")
@@ -224,19 +305,25 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- scene (replicated) and inputs, resident in HBM before the timed region ----
-    mesh = synth.make_scene(args.scene)
+    if args.mesh:
+        from lidarcast import ply
+        mesh = ply.read_triangle_mesh(args.mesh)
+        args.scene = os.path.basename(args.mesh)
+    else:
+        mesh = synth.make_scene(args.scene)
     ctx = lidarcast.Context(local_rank)
     v32 = np.ascontiguousarray(mesh.vertices, dtype=np.float32)
     f32 = np.ascontiguousarray(mesh.triangles, dtype=np.uint32)
     t0 = time.perf_counter()
-    scene = lidarcast.Scene(ctx, v32, f32, mesh.triangle_sem, mesh.triangle_ins)
+    tri_sem, tri_ins = getattr(mesh, "triangle_sem", None), getattr(mesh, "triangle_ins", None)
+    scene = lidarcast.Scene(ctx, v32, f32, tri_sem, tri_ins)
     create_first_ms = (time.perf_counter() - t0) * 1e3      # includes the builder's one-time scratch allocation
     info = scene.info
     create_ms = []
     if rank == 0:
         for _ in range(3):                                   # steady state: the next mesh of a batch
             t0 = time.perf_counter()
-            again = lidarcast.Scene(ctx, v32, f32, mesh.triangle_sem, mesh.triangle_ins)
+            again = lidarcast.Scene(ctx, v32, f32, tri_sem, tri_ins)
             create_ms.append((time.perf_counter() - t0) * 1e3)
             again_info = again.info
             again.close()
@@ -245,6 +332,12 @@ def main():
         raise SystemExit("--virtual-world needs --dist-selftest on one GPU")
     job = world if world > 1 else max(args.virtual_world, 1)      # ranks the buffers and the rebuild are sized for
     poses = c3_poses(rank, job)
+    if args.mesh:        # the same line of poses, through the middle of this mesh's bounding box at a third of its height
+        lo, hi = v32.min(0).astype(np.float64), v32.max(0).astype(np.float64)
+        frac = (poses[:, 0, 3] - 1.0) / 3.0
+        poses[:, 0, 3] = lo[0] + (0.2 + 0.6 * frac) * (hi[0] - lo[0])
+        poses[:, 1, 3] = 0.5 * (lo[1] + hi[1])
+        poses[:, 2, 3] = lo[2] + (hi[2] - lo[2]) / 3.0
     dirs = IndoorLidar(intrinsics=sensor, pose=np.eye(4)).sensor_directions()
     P, N = poses.shape[0], dirs.shape[0]
     n = P * N
@@ -283,6 +376,14 @@ def main():
     else:
         gathers = None
 
+    # N = 1 (default): the library's scan pipeline; its rows go to three rotating output buffers (a submit's rows are written
+    # up to two submits later).  The bytes are checked against the two-call step below, in this run.
+    use_pipe = not dist_path and not args.serial
+    if use_pipe:
+        pipe = lidarcast.ScanPipe(scene, P, N)
+        pipe_rows = [cloud] + [torch.empty_like(cloud) for _ in range(2)]
+        pipe_counts = [counts] + [torch.zeros_like(counts) for _ in range(2)]
+
     k_events = []
     state = {"i": 0, "pending": None}
     if gathers is not None:
@@ -314,9 +415,14 @@ def main():
         rebuilt[k] = ev
 
     def step(timed):
-        if timed:
+        if timed and not use_pipe:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        if use_pipe:
+            j = state["i"] % 3
+            state["i"] += 1
+            pipe.submit(d_poses, d_dirs, sensor.max_range, out_rows_t=pipe_rows[j], counts_t=pipe_counts[j], stream=stream)
+            return
         if gathers is None:
             scene.scan_poses_dev(d_poses, d_dirs, hits, sensor.max_range, stream)
             if timed:
@@ -345,6 +451,8 @@ def main():
         state["pending"] = k
 
     def drain():
+        if use_pipe:
+            pipe.wait(stream)          # scatters the rows still in the pipeline, orders this stream behind everything
         if gathers is not None:
             if state["pending"] is not None:
                 rebuild(state["pending"])
@@ -357,30 +465,72 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def serial_step(timed):
+        """the step as two calls on one stream: trace launch (timed alone by HIP events) + compaction"""
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        scene.scan_poses_dev(d_poses, d_dirs, hits, sensor.max_range, stream)
+        if timed:
+            e1.record()
+            k_events.append((e0, e1))
+        ctx.compact_dev(P, N, io, stream)
+
+    serial_ms = None
+    if use_pipe:
+        # (1) the un-pipelined step on this box: gives the trace launch's own duration (HIP events on its stream; what the
+        # roofline is priced with and what rocprofv3 reports for `bench.py --serial`) and the figure the pipeline is held against
+        serial_rows, serial_counts = torch.empty_like(cloud), torch.zeros_like(counts)
+        io.out_xyzl, io.counts = serial_rows.data_ptr(), serial_counts.data_ptr()
+        for _ in range(5):
+            serial_step(False)
+        torch.cuda.synchronize()
+        sb = []
+        for _ in range(12):
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                serial_step(True)
+            torch.cuda.synchronize()
+            sb.append((time.perf_counter() - t0) / args.steps)
+        serial_ms = float(np.median(sb)) * 1e3
+
     for _ in range(args.warmup):
         step(False)
     barrier()
     # EXACTLY --steps steps form one timed block, bracketed by barrier + synchronize on both sides.  A block of the
-    # default 20 steps lasts ~9 ms, too short for a stable figure (clock ramp), so the block is repeated until
-    # MIN_TIMED_SECONDS have passed and the MEDIAN block is reported; value = rays of one block / its time.
+    # default 20 steps lasts ~7 ms, too short for a stable figure (clock ramp) and for the driver's GPU-busy sampler, so
+    # the block is repeated until --min-seconds have passed -- half of them before the host legs (CPU baseline, caller
+    # path), half after -- and the MEDIAN block is reported; value = rays of one block / its time.
     blocks = []
-    t_begin = time.perf_counter()
-    while True:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(True)
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([dt, time.perf_counter() - t_begin], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt, total_elapsed = float(tmax[0].item()), float(tmax[1].item())       # every rank takes the same decision
-        else:
-            total_elapsed = time.perf_counter() - t_begin
-        blocks.append(dt)
-        if total_elapsed >= MIN_TIMED_SECONDS or len(blocks) >= 4096:
-            break
-    elapsed = float(np.median(blocks))
+
+    def timed_blocks(seconds):
+        t_begin = time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step(True)
+            barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                tmax = torch.tensor([dt, time.perf_counter() - t_begin], dtype=torch.float64, device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt, total_elapsed = float(tmax[0].item()), float(tmax[1].item())       # every rank takes the same decision
+            else:
+                total_elapsed = time.perf_counter() - t_begin
+            blocks.append(dt)
+            if total_elapsed >= seconds or len(blocks) >= 1 << 16:
+                break
+
+    host_legs = rank == 0 and world == 1 and not args.dist_selftest
+    timed_blocks(args.min_seconds * (0.5 if host_legs else 1.0))
+
+    if use_pipe:
+        # the pipeline's rows are the two-call step's rows, bit for bit (all three rotating buffers)
+        kk = int(serial_counts.sum().item())
+        for r_, c_ in zip(pipe_rows, pipe_counts):
+            assert torch.equal(c_, serial_counts), "scan pipeline: per-pose counts differ from the two-call step"
+            assert torch.equal(r_[:kk].view(torch.int32), serial_rows[:kk].view(torch.int32)), \
+                "scan pipeline: rows differ from the two-call step"
 
     if args.dist_selftest:
         # the cloud rebuilt from the gathered triangle ids must equal the local compaction, bit for bit
@@ -406,8 +556,6 @@ def main():
               f"world {world}, buffers sized for {job} ranks", file=sys.stderr)
     kernel_ms = float(np.median([a.elapsed_time(b) for a, b in k_events]))
     hits_total = int(counts.sum().item())
-    total_rays = n * world * args.steps
-    value = total_rays / elapsed
     bpr = bytes_per_ray(info["num_triangles"])
     pmc = pmc_profile("void (anonymous namespace)::trace_kernel<1", n, args.scene)
     kernel_s = kernel_ms * 1e-3
@@ -450,6 +598,9 @@ def main():
                     "(source fingerprint, kernel, scene or ray count differ): run tools/pmc.sh"}
     roofline.update({
         "kernel": "trace_kernel<GEN=1>", "kernel_ms": kernel_ms, "rays_per_launch": n,
+        "kernel_ms_note": ("one un-overlapped trace launch, HIP events on its stream (the serial steps timed before the "
+                           "pipelined blocks); `bench.py --serial` under rocprofv3 --stats reports the same launch"
+                           if use_pipe else "HIP events on the launch stream over the timed region"),
         "survey_8d_model": {"bytes_per_ray": bpr, "algorithmic_bytes_per_launch": n * bpr,
                             "algorithmic_GBps": n * bpr / kernel_s / 1e9,
                             "note": "SURVEY 8(d) per-ray figure (36 B record + 64 B x ceil(log2(T/4)) descent + 144 B "
@@ -460,8 +611,23 @@ def main():
                 "profiles/pmc_latest.json, divided by the kernel time measured live with HIP events on the launch "
                 "stream); peak = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz; frac = valu_issue_frac x lane_utilisation",
     })
-    caller = caller_path(scene, sensor, poses, dirs, mesh) if (rank == 0 and world == 1 and not args.dist_selftest
-                                                                and not args.no_caller_path) else {}
+    caller = caller_path(scene, sensor, poses, dirs, mesh) if (host_legs and not args.no_caller_path) else {}
+    cpu = cpu_baseline(mesh, sensor, poses) if (host_legs and not args.no_cpu_baseline) else None
+    if host_legs:
+        timed_blocks(args.min_seconds * 0.5)          # the second half of the timed blocks, after the host legs
+    elapsed = float(np.median(blocks))
+    total_rays = n * world * args.steps
+    value = total_rays / elapsed
+    if use_pipe and pmc is not None:
+        # inside the pipeline a launch overlaps its neighbours, so it has no duration of its own; what it costs is at most the
+        # step (which also holds the compaction): the VALU work of one launch over ms_per_step is a LOWER bound on what the
+        # pipes deliver while the pipeline runs
+        step_s = elapsed / args.steps
+        roofline["in_pipeline"] = {
+            "ms_per_step": step_s * 1e3,
+            "frac_lower_bound": lane_ops / step_s / 1e9 / VALU_PEAK_GLANEOPS,
+            "valu_issue_frac_lower_bound": pmc["SQ_INSTS_VALU"] * 2.0 / (N_SIMDS * CLOCK_GHZ * 1e9 * step_s),
+            "note": "trace-launch VALU work (the isolated launch's counters) / the whole pipelined step, compaction included"}
 
     if rank == 0:
         res = {
@@ -486,6 +652,16 @@ def main():
                                      "(csrc/lrc_bvh_device.hip); median of 3 re-creations, first = with the builder's "
                                      "one-time scratch allocation.  The reference pays an Embree build per POSE",
                 "trajectory_including_scene_create_rays_per_s": n / (float(np.median(create_ms)) * 1e-3 + elapsed / args.steps),
+                "step_arrangement": ("scan pipeline (lrc_pipe_*): the trace launches of consecutive steps alternate between two "
+                                     "internal streams, the rows of step k are scattered by the leading workgroups of the trace "
+                                     "launch of step k+2; rows and counts checked in this run against the two-call step, bit for bit"
+                                     if use_pipe else
+                                     ("two calls on one stream: lrc_scan_poses_dev + lrc_compact_dev (--serial)" if not dist_path
+                                      else "one process per GPU: trace + all-gather + cloud assembly, double buffered")),
+                **({"serial_ms_per_step": serial_ms,
+                    "serial_note": "the same step as lrc_scan_poses_dev + lrc_compact_dev on one stream, same box, same run "
+                                   "(median of 12 blocks); roofline.kernel_ms is the trace launch of THESE steps, alone on the "
+                                   "chip"} if serial_ms is not None else {}),
                 "caller_path_note": "value is the device-resident loop; caller_path_rays_per_s is what a host caller of "
                                     "the plugin surface gets (kept rows in page-locked host memory, PCIe included)",
                 "step": "in-kernel ray generation + BVH traversal + hit write-back (36 B/ray) + "
@@ -500,9 +676,9 @@ def main():
         res["timed"] = {"blocks": len(blocks), "block_steps": args.steps, "block_ms_median": elapsed * 1e3,
                         "block_ms_min": min(blocks) * 1e3, "block_ms_max": max(blocks) * 1e3,
                         "note": "value = rays of one block of --steps steps / the median block time"}
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(mesh, sensor, poses)
-            res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        if cpu is not None:
+            res["cpu_baseline"] = cpu
+            res["cpu_baseline"]["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(res))
     if world > 1 or args.dist_selftest:
         dist.destroy_process_group()

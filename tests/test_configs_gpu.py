@@ -274,7 +274,9 @@ def test_c5_six_scenes_full_size(engine):
     print("\n[C5]", {k: v for k, v in report.items() if k != "scenes"})
     print("[C5] per scene, scan + build ms (the first scene's scan page-locks the frame buffers the others reuse):",
           " ".join(f"{n}:{v['seconds'] * 1e3:.1f}+{v['build_seconds'] * 1e3:.1f}" for n, v in report["scenes"].items()))
-    assert report["rays_per_s"] > 2e7
+    # a guard that guards: round 3 measured 0.29-0.38 G rays/s including the builds (0.02 G with the round-2 host builder,
+    # which this bound rejects); the check_scene callback's oracle work is outside both clocks
+    assert report["rays_per_s_including_build"] > 2e8 and report["rays_per_s"] > 3e8, report
 
 
 # ---- C4: BLK2GO, 256 poses -----------------------------------------------------------------------------------
@@ -846,3 +848,42 @@ def test_quantised_images_on_random_scenes(engine, monkeypatch):
             assert np.array_equal(a["prim"][pick], p_bf)
         q.close(); w.close()
     assert used >= 6          # most of these scenes take the grid (those offset by three widths do not)
+
+
+# ---- the reference's own arithmetic, where the measuring host has it ----------------------------------------------------
+def test_hip_against_open3d_cast_rays(engine):
+    """The ONE thing that can pin parity at the Embree boundary: Open3D's
+    RaycastingScene.cast_rays -- the call the reference makes at raycast_engine_cpu.py:46-51 -- on the same float32 rays as the
+    HIP engine: C2 (8 x 512 in synth_A1_office) and three poses of C3.  Hit mask equal except on rays whose float64 witness
+    puts the hit within 1e-6 of a triangle edge (or that graze a seam), |t_hip - t_open3d| <= 1e-5 m (north star), the same
+    triangle row.  Skipped where Open3D is not installed (it is absent on this pool's boxes: DESIGN.md section 7)."""
+    o3d = pytest.importorskip("open3d")
+    import bench
+    from lidar import create_lidar
+    from lidarcast import synth
+    from oracle.c_oracle import OracleMesh
+    cases = [("C2", "synth_A1_office", sensor_8x512(), [pose(4.0, 3.0, 1.0)]),
+             ("C3", bench.SCENE, bench.c3_sensor(), list(bench.c3_poses(0, 1)[[0, 31, 63]]))]
+    for name, scene_name, sensor, poses in cases:
+        mesh = synth.make_scene(scene_name)
+        rays = np.concatenate([create_lidar(sensor, m).get_rays() for m in poses]).astype(np.float32)
+        out = engine.cast_rays(rays, mesh)
+        legacy = o3d.geometry.TriangleMesh(o3d.utility.Vector3dVector(np.asarray(mesh.vertices, dtype=np.float64)),
+                                           o3d.utility.Vector3iVector(np.asarray(mesh.triangles, dtype=np.int32)))
+        sc = o3d.t.geometry.RaycastingScene()
+        sc.add_triangles(o3d.t.geometry.TriangleMesh.from_legacy(legacy))
+        ans = sc.cast_rays(o3d.core.Tensor(rays))
+        t_ref, p_ref = ans["t_hit"].numpy(), ans["primitive_ids"].numpy()
+        t_hip, p_hip = out["t_hit"], out["primitive_ids"]
+        h_ref, h_hip = np.isfinite(t_ref), np.isfinite(t_hip)
+        _, _, margin = OracleMesh(mesh.vertices, mesh.triangles).witness(rays, threads=16)
+        differ = h_ref != h_hip
+        both = h_ref & h_hip
+        dt = np.abs(t_ref[both].astype(np.float64) - t_hip[both].astype(np.float64))
+        other = both & (p_ref != p_hip)
+        print(f"\n[open3d {o3d.__version__}] {name}: rays {len(rays)}, both hit {int(both.sum())}, hit/miss disagreements "
+              f"{int(differ.sum())} (of them with witness margin >= 1e-6: {int((differ & (margin >= 1e-6)).sum())}), other "
+              f"triangle {int(other.sum())}, max |dt| {dt.max():.3e} m, bit-equal t {int((t_ref[both] == t_hip[both]).sum())}")
+        assert not (differ & (margin >= 1e-6)).any(), "hit mask differs from Open3D away from triangle edges"
+        assert dt.max() <= 1e-5
+        assert (margin[other] < 1e-4).all(), "another triangle than Open3D's away from a shared edge"

@@ -810,7 +810,7 @@ def test_bench_contract():
     import subprocess
     import sys
     from conftest import REPO
-    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1"],
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "20", "--warmup", "3", "--min-seconds", "0.6"],
                          capture_output=True, text=True, timeout=600, check=True).stdout
     line = [l for l in out.splitlines() if l.startswith("{")]
     assert len(line) == 1
@@ -818,16 +818,22 @@ def test_bench_contract():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in r, k
-    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["unit"] == "rays/s" and r["vs_baseline"] is None
-    assert "workload" in r["config"] and r["value"] > 1e8
+    assert r["n_gpus"] == 1 and r["steps"] == 20 and r["unit"] == "rays/s" and r["vs_baseline"] is None
+    # throughput guards that guard: the round-3 step did 11.3 G rays/s on the slowest box seen (a regression to the round-2
+    # kernel or to a host-built scene lands below), and the pipelined step must not be slower than the two calls it replaces
+    assert "workload" in r["config"] and r["value"] > 8e9
+    assert r["config"]["step_arrangement"].startswith("scan pipeline")
+    assert r["ms_per_step"] <= r["config"]["serial_ms_per_step"] * 1.01, (r["ms_per_step"], r["config"]["serial_ms_per_step"])
+    assert r["config"]["scene_create_ms"] < 20.0                     # the device builder (a host build takes 130+ ms)
     rf = r["roofline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rf) and rf["bound"] == "valu"
     if rf["frac"] is not None:       # counters of THIS binary are committed (profiles/pmc_latest.json matches the sources)
         assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.0 < rf["frac"] <= 1.0
         assert abs(rf["frac"] - rf["valu_issue_frac"] * rf["lane_utilisation"]) < 1e-6
         assert rf["traffic"] > 0 and rf["hbm_side"]["frac_of_hbm_peak"] < 1.0
-    assert r["timed"]["blocks"] >= 1 and r["config"]["caller_path_rays_per_s"] > 1e8
-    assert set(("value", "unit", "cores", "kind", "sample")) <= set(r["cpu_baseline"]) and r["cpu_baseline"]["kind"] == "port"
+    assert r["timed"]["blocks"] >= 2 and r["config"]["caller_path_rays_per_s"] > 1.5e9
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(r["cpu_baseline"])
+    assert r["cpu_baseline"]["kind"] == ("port" if "not installed" in r["cpu_baseline"].get("open3d", "") else "reference")
 
 
 def test_two_rank_launch_of_the_bench_path():

@@ -66,20 +66,54 @@ class S3DISSimFrame:
     def __init__(self, frame_index: int, points: np.ndarray, incident_angles: np.ndarray,
                  scan_quality: ScanQuality, frame_metadata: Optional[Dict[str, Any]] = None,
                  semantic_labels: Optional[np.ndarray] = None,
-                 instance_labels: Optional[np.ndarray] = None):
+                 instance_labels: Optional[np.ndarray] = None, label_source=None):
         self.frame_index = frame_index
         self.points = points
         self.incident_angles = incident_angles
         self.scan_quality = scan_quality
         self.frame_metadata = frame_metadata or {}
-        self.semantic_labels = semantic_labels
-        self.instance_labels = instance_labels
+        # The reference's frame carries no labels (containers/s3dis_sim_frame.py:90-101); this one offers the hit triangles'
+        # as an extra.  They are either handed in, or fetched on first access from ``label_source`` (an object whose
+        # ``frame_labels(i)`` returns (semantic, instance) of frame i): S3DISSimulator.run_simulation does not move four
+        # of every sixteen bytes across PCIe for a caller who never looks at them.
+        self._semantic_labels = semantic_labels
+        self._instance_labels = instance_labels
+        self._label_source = label_source
         if len(points) != len(incident_angles):
             raise ValueError(f"Point cloud count ({len(points)}) does not match incident angle count "
                              f"({len(incident_angles)})")
         for lab in (semantic_labels, instance_labels):
             if lab is not None and len(lab) != len(points):
                 raise ValueError("label count does not match point cloud count")
+
+    def _fetch_labels(self):
+        src, self._label_source = self._label_source, None
+        if src is not None:
+            self._semantic_labels, self._instance_labels = src.frame_labels(self.frame_index)
+
+    @property
+    def semantic_labels(self):
+        if self._label_source is not None:
+            self._fetch_labels()
+        return self._semantic_labels
+
+    @semantic_labels.setter
+    def semantic_labels(self, value):
+        if self._label_source is not None:
+            self._fetch_labels()
+        self._semantic_labels = value
+
+    @property
+    def instance_labels(self):
+        if self._label_source is not None:
+            self._fetch_labels()
+        return self._instance_labels
+
+    @instance_labels.setter
+    def instance_labels(self, value):
+        if self._label_source is not None:
+            self._fetch_labels()
+        self._instance_labels = value
 
     def get_num_points(self) -> int:
         return len(self.points)

@@ -118,6 +118,8 @@ struct lrc_ctx {
     uint64_t* h_counts = nullptr;       // page-locked landing area of the per-pose counts and statistics (async copies
     uint64_t h_counts_cap = 0;          // need one): counts (P u64) | 4 x P doubles of per-pose statistics
     lrc::DeviceArena build_arena;       // scratch of the device scene build, reused from scene to scene
+    float* stat_scratch = nullptr;      // chunk sums of lrc_cloud_range_stats_dev (calls of one context must not overlap
+    uint64_t stat_scratch_cap = 0;      // on different streams: handles are not thread-safe)
 };
 
 struct lrc_table {            // a sensor's direction table resident in HBM (lrc_table_create)
@@ -1415,6 +1417,7 @@ int lrc_ctx_destroy(lrc_ctx* ctx) {
     for (hipEvent_t e : ctx->ev_chunk) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_compact) if (e) (void)hipEventDestroy(e);
     if (ctx->chain_word) (void)hipFree(ctx->chain_word);
+    if (ctx->stat_scratch) (void)hipFree(ctx->stat_scratch);
     for (hipEvent_t e : ctx->compact_done) if (e) (void)hipEventDestroy(e);
     for (lrc_ctx::TileScratch* sc : {&ctx->compact_scratch[0], &ctx->compact_scratch[1], &ctx->compact_scratch[2],
                                      &ctx->compact_scratch[3], &ctx->cloud_scratch}) {
@@ -2691,8 +2694,13 @@ int lrc_cloud_range_stats_dev(lrc_ctx* ctx, const float* d_xyzl, const uint64_t*
     if (max_rows)
         hipLaunchKernelGGL(rows_range_kernel, dim3((uint32_t)((max_rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                            (const float4*)d_xyzl, max_rows, d_range);
-    hipLaunchKernelGGL(segment_stats_kernel<float>, dim3((uint32_t)num_poses), dim3(256), 0, st, (const float*)d_range,
-                       d_counts, (uint64_t)0, num_poses, d_mean, d_std);
+    const uint64_t need = segment_stats_scratch_values(num_poses, max_rows);
+    if (ctx->stat_scratch_cap < need) {
+        if (ctx->stat_scratch) { LRC_HIP(hipDeviceSynchronize()); (void)hipFree(ctx->stat_scratch); ctx->stat_scratch = nullptr; ctx->stat_scratch_cap = 0; }
+        LRC_HIP(hipMalloc((void**)&ctx->stat_scratch, (need + need / 4) * 4));
+        ctx->stat_scratch_cap = need + need / 4;
+    }
+    launch_segment_stats<float>(st, (const float*)d_range, d_counts, (uint64_t)0, num_poses, ctx->stat_scratch, d_mean, d_std);
     LRC_HIP(hipGetLastError());
     return LRC_OK;
 }
@@ -2765,6 +2773,7 @@ struct FrameStage {
     lrc_hits rec{};
     lrc_compact_io io{};
     double* d_stats = nullptr;
+    uint64_t stat_partial = 0;                                // values of chunk-sum scratch per column, behind the 4 P results
     int alloc(lrc_ctx* ctx, const lrc_frames& f, uint64_t P, uint64_t n) {
         int rc;
         const bool rstats = f.range_origin_mean || f.range_origin_std, istats = f.incident_mean || f.incident_std;
@@ -2776,7 +2785,12 @@ struct FrameStage {
         if (want_sem) { if ((rc = sem.get(ctx, kPoolSem, n * 2))) return rc; rec.sem = (uint16_t*)sem.p; }
         if (want_ins) { if ((rc = ins.get(ctx, kPoolIns, n * 2))) return rc; rec.ins = (uint16_t*)ins.p; }
         if (f.incident_deg || istats) { if ((rc = inc.get(ctx, kPoolInc, n * 8))) return rc; rec.incident_deg = (double*)inc.p; }
-        if (rstats || istats) { if ((rc = fstat.get(ctx, kPoolFrameStats, P * 8 * 4))) return rc; d_stats = (double*)fstat.p; }
+        if (rstats || istats) {
+            // 4 x P doubles of results, then the chunk sums of the two columns (segment_chunk_sums_kernel)
+            stat_partial = segment_stats_scratch_values(P, n);
+            if ((rc = fstat.get(ctx, kPoolFrameStats, (P * 4 + 2 * stat_partial) * 8))) return rc;
+            d_stats = (double*)fstat.p;
+        }
         if ((rc = tile.get(ctx, kPoolTile, ((n + 63) / 64 + 1) * 4))) return rc;
         rec.tile_count = (uint32_t*)tile.p;
         io.t = rec.t; io.point3 = rec.point3; io.sem = rec.sem; io.ins = rec.ins; io.incident_deg = rec.incident_deg;
@@ -2881,14 +2895,14 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
             float* rm = (float*)st.d_stats;            float* rs = (float*)(st.d_stats + P);
             double* im = st.d_stats + 2 * P;           double* is = st.d_stats + 3 * P;
             if (out->range_origin_mean || out->range_origin_std) {
-                hipLaunchKernelGGL(segment_stats_kernel<float>, dim3((uint32_t)P), dim3(256), 0, cs,
-                                   (const float*)st.io.out_range_origin, (const uint64_t*)st.io.counts, (uint64_t)0, P, rm, rs);
+                launch_segment_stats<float>(cs, (const float*)st.io.out_range_origin, (const uint64_t*)st.io.counts, (uint64_t)0, P,
+                                            (float*)(st.d_stats + 4 * P), rm, rs);
                 LRC_HIP(hipMemcpyAsync((float*)hs, rm, P * 4, hipMemcpyDeviceToHost, cs));
                 LRC_HIP(hipMemcpyAsync((float*)(hs + ctx->h_counts_cap), rs, P * 4, hipMemcpyDeviceToHost, cs));
             }
             if (out->incident_mean || out->incident_std) {
-                hipLaunchKernelGGL(segment_stats_kernel<double>, dim3((uint32_t)P), dim3(256), 0, cs,
-                                   (const double*)st.io.out_incident_deg, (const uint64_t*)st.io.counts, (uint64_t)0, P, im, is);
+                launch_segment_stats<double>(cs, (const double*)st.io.out_incident_deg, (const uint64_t*)st.io.counts, (uint64_t)0, P,
+                                             st.d_stats + 4 * P + st.stat_partial, im, is);
                 LRC_HIP(hipMemcpyAsync(hs + 2 * ctx->h_counts_cap, im, P * 8, hipMemcpyDeviceToHost, cs));
                 LRC_HIP(hipMemcpyAsync(hs + 3 * ctx->h_counts_cap, is, P * 8, hipMemcpyDeviceToHost, cs));
             }
@@ -2961,16 +2975,14 @@ int frames_finish(lrc_scene* s, TraceParams& p, int gen, FrameStage& st, uint64_
             double* im = st.d_stats + 2 * P;           double* is = st.d_stats + 3 * P;
             double* hs = (double*)(ctx->h_counts + ctx->h_counts_cap);
             if (out->range_origin_mean || out->range_origin_std) {
-                hipLaunchKernelGGL(segment_stats_kernel<float>, dim3((uint32_t)np_), dim3(256), 0, ss,
-                                   (const float*)st.io.out_range_origin, (const uint64_t*)(st.io.counts + p0), r0, np_,
-                                   rm + p0, rs + p0);
+                launch_segment_stats<float>(ss, (const float*)st.io.out_range_origin, (const uint64_t*)(st.io.counts + p0), r0, np_,
+                                            (float*)(st.d_stats + 4 * P) + r0 / 8192 + p0, rm + p0, rs + p0);
                 LRC_HIP(hipMemcpyAsync((float*)hs + p0, rm + p0, np_ * 4, hipMemcpyDeviceToHost, ss));
                 LRC_HIP(hipMemcpyAsync((float*)(hs + ctx->h_counts_cap) + p0, rs + p0, np_ * 4, hipMemcpyDeviceToHost, ss));
             }
             if (out->incident_mean || out->incident_std) {
-                hipLaunchKernelGGL(segment_stats_kernel<double>, dim3((uint32_t)np_), dim3(256), 0, ss,
-                                   (const double*)st.io.out_incident_deg, (const uint64_t*)(st.io.counts + p0), r0, np_,
-                                   im + p0, is + p0);
+                launch_segment_stats<double>(ss, (const double*)st.io.out_incident_deg, (const uint64_t*)(st.io.counts + p0), r0, np_,
+                                             st.d_stats + 4 * P + st.stat_partial + r0 / 8192 + p0, im + p0, is + p0);
                 LRC_HIP(hipMemcpyAsync(hs + 2 * ctx->h_counts_cap + p0, im + p0, np_ * 8, hipMemcpyDeviceToHost, ss));
                 LRC_HIP(hipMemcpyAsync(hs + 3 * ctx->h_counts_cap + p0, is + p0, np_ * 8, hipMemcpyDeviceToHost, ss));
             }

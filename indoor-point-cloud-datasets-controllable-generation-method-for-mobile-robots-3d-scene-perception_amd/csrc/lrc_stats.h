@@ -129,29 +129,70 @@ __device__ T block_reduce_numpy(const T* a, uint64_t n, T mean, T* s_leaf /* 64 
     return total;
 }
 
-// one workgroup per segment (frame): mean and population standard deviation of its values, numpy's way
-template <typename T>
-__global__ __launch_bounds__(256) void segment_stats_kernel(const T* values, const uint64_t* counts, uint64_t first_row,
-                                                            uint64_t num_segments, T* out_mean, T* out_std) {
-    __shared__ T s_leaf[64 * kStatBatch];
-    __shared__ T s_mean;
-    const uint64_t seg = blockIdx.x;
-    if (seg >= num_segments) return;
-    uint64_t start = first_row;
+// ---- mean and population standard deviation per segment (frame), numpy's way, one workgroup per 8192-element CHUNK ----------
+// np.add.reduce adds the pairwise sums of the buffer chunks left to right, so the chunks of all frames are independent: kStatPar
+// workgroups per frame stride over its chunks (64 frames of ~65 k values: 512 workgroups instead of the 64 the first version
+// ran -- 310 us, a hundredth of the memory rate), then one thread per frame adds its chunk sums in chunk order, divides, and
+// the same again for the squares.  Chunk c of segment s (first row start_s) lands in partial[start_s / 8192 + s + c]: the
+// ranges of different segments never overlap (floor(a + b) >= floor(a) + floor(b)), total rows / 8192 + segments + 1 values.
+constexpr uint32_t kStatPar = 8;
+
+__device__ __forceinline__ uint64_t segment_start(const uint64_t* counts, uint64_t first_row, uint64_t seg) {
+    uint64_t start = first_row;                      // a few hundred counts at most, L2 resident
     for (uint64_t k = 0; k < seg; ++k) start += counts[k];
+    return start;
+}
+
+template <typename T, bool SQ>
+__global__ __launch_bounds__(256) void segment_chunk_sums_kernel(const T* values, const uint64_t* counts, uint64_t first_row,
+                                                                 uint64_t num_segments, const T* mean, T* partial) {
+    __shared__ T s_leaf[64 * kStatBatch];
+    const uint64_t seg = blockIdx.x / kStatPar;
+    if (seg >= num_segments) return;
     const uint64_t n = counts[seg];
-    if (n == 0) {
-        if (threadIdx.x == 0) { out_mean[seg] = (T)0; out_std[seg] = (T)0; }
-        return;
+    const uint64_t start = segment_start(counts, first_row, seg);
+    T* out = partial + (start - first_row) / 8192 + seg;
+    const T m = SQ ? mean[seg] : (T)0;
+    for (uint64_t c = blockIdx.x - seg * kStatPar; c * 8192 < n; c += kStatPar) {
+        const uint64_t left = n - c * 8192;
+        const T sum = block_reduce_numpy<T, SQ>(values + start + c * 8192, left < 8192 ? left : 8192, m, s_leaf);
+        if (threadIdx.x == 0) out[c] = sum;
+        __syncthreads();
     }
-    const T* a = values + start;
-    const T sum = block_reduce_numpy<T, false>(a, n, (T)0, s_leaf);
-    if (threadIdx.x == 0) s_mean = sum / (T)n;
-    __syncthreads();
-    const T mean = s_mean;
-    const T ss = block_reduce_numpy<T, true>(a, n, mean, s_leaf);
-    if (threadIdx.x == 0) {
-        out_mean[seg] = mean;
-        out_std[seg] = sizeof(T) == 4 ? (T)__builtin_sqrtf((float)(ss / (T)n)) : (T)__builtin_sqrt((double)(ss / (T)n));
-    }
+}
+
+// SQ = false: out[seg] = mean = (chunk sums added left to right) / n.  SQ = true: out[seg] = sqrt(that sum / n).
+template <typename T, bool SQ>
+__global__ __launch_bounds__(256) void segment_combine_kernel(const T* partial, const uint64_t* counts, uint64_t first_row,
+                                                              uint64_t num_segments, T* out) {
+    const uint64_t seg = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (seg >= num_segments) return;
+    const uint64_t n = counts[seg];
+    if (n == 0) { out[seg] = (T)0; return; }
+    const uint64_t nch = (n + 8191) / 8192;
+    const T* p = partial + (segment_start(counts, first_row, seg) - first_row) / 8192 + seg;
+    T total = p[0];
+    for (uint64_t c = 1; c < nch; ++c) total = total + p[c];
+    const T q = total / (T)n;
+    if (!SQ) out[seg] = q;
+    else out[seg] = sizeof(T) == 4 ? (T)__builtin_sqrtf((float)q) : (T)__builtin_sqrt((double)q);
+}
+
+// values of scratch a call over `rows` rows in `num_segments` segments needs
+inline uint64_t segment_stats_scratch_values(uint64_t num_segments, uint64_t rows) { return rows / 8192 + num_segments + 2; }
+
+// four launches on `st`; `partial`: segment_stats_scratch_values(...) values of scratch the caller owns on that stream
+template <typename T>
+void launch_segment_stats(hipStream_t st, const T* values, const uint64_t* counts, uint64_t first_row, uint64_t num_segments,
+                          T* partial, T* out_mean, T* out_std) {
+    if (num_segments == 0) return;
+    const uint32_t grid = (uint32_t)(num_segments * kStatPar), cgrid = (uint32_t)((num_segments + 255) / 256);
+    hipLaunchKernelGGL((segment_chunk_sums_kernel<T, false>), dim3(grid), dim3(256), 0, st, values, counts, first_row,
+                       num_segments, (const T*)nullptr, partial);
+    hipLaunchKernelGGL((segment_combine_kernel<T, false>), dim3(cgrid), dim3(256), 0, st, (const T*)partial, counts, first_row,
+                       num_segments, out_mean);
+    hipLaunchKernelGGL((segment_chunk_sums_kernel<T, true>), dim3(grid), dim3(256), 0, st, values, counts, first_row,
+                       num_segments, (const T*)out_mean, partial);
+    hipLaunchKernelGGL((segment_combine_kernel<T, true>), dim3(cgrid), dim3(256), 0, st, (const T*)partial, counts, first_row,
+                       num_segments, out_std);
 }

@@ -156,6 +156,33 @@ class PinnedPool:
         weakref.finalize(raw, PinnedPool._release, weakref.ref(self), ptr, k, self._ctx)
         return np.frombuffer(raw, dtype=np.uint8, count=k)
 
+    def reserve(self, sizes):
+        """Page-lock blocks of these sizes NOW and put them on the free lists, so that the first trajectory's frame arrays do
+        not pay hipHostMalloc (28-30 ms for the 67 MB of a C3 trajectory) inside the caller's first scan.  Meant to be
+        called once, at engine construction, from a helper thread while the caller loads its mesh."""
+        for nbytes in sizes:
+            k = self._klass(max(int(nbytes), 1))
+            with self._lock:
+                if self._free_bytes + k > self._max_free:
+                    return
+            p = C.c_void_p()
+            try:
+                check(self._ctx._lib.lrc_host_alloc(self._ctx._h, k, C.byref(p)), "lrc_host_alloc")
+            except Exception:
+                return
+            with self._lock:
+                self.allocations += 1
+                self._free.setdefault(k, []).append(p.value)
+                self._free_bytes += k
+
+    _reserve_thread = None
+
+    def reserve_async(self, sizes):
+        """``reserve`` on a helper thread; ``clear`` (and with it Context.close) waits for it."""
+        import threading
+        self._reserve_thread = threading.Thread(target=self.reserve, args=(tuple(sizes),), daemon=True)
+        self._reserve_thread.start()
+
     @staticmethod
     def _release(pool_ref, ptr, k, ctx):
         pool = pool_ref()
@@ -171,6 +198,9 @@ class PinnedPool:
             ctx._lib.lrc_host_free(ctx._h, C.c_void_p(ptr))
 
     def clear(self):
+        t, self._reserve_thread = self._reserve_thread, None
+        if t is not None:
+            t.join()
         with self._lock:
             self._slab = None
             lists = list(self._free.values())

@@ -8,6 +8,7 @@ caller turns into its own fallback decision (s3dis_simulator.py:66-74).
 """
 import hashlib
 import itertools
+import os
 import weakref
 
 import numpy as np
@@ -147,11 +148,21 @@ def dual_axis_rays_batch(lidars, rays, keep):
 class RaycastEngineHIP(RaycastEngineBase):
     """HIP (gfx950) engine.  ``RaycastEngineGPU`` is this class."""
 
-    def __init__(self, verbose=False, device=0, max_cached_scenes=4, cache_check="sampled"):
+    # page-locked host blocks reserved at construction: the frame arrays of one 32 x 2048 x 64-pose trajectory (points 50 MB ->
+    # a 64 MB block, labels 8.4 MB -> 16 MB blocks each); () or LRC_PRELOCK=0 reserves nothing
+    PRELOCK_BYTES = (64 << 20, 16 << 20, 16 << 20)
+
+    def __init__(self, verbose=False, device=0, max_cached_scenes=4, cache_check="sampled", prelock_bytes=None):
         super().__init__()
         self.verbose = verbose
         self.cache_check = cache_check      # "sampled" | "full": see _fingerprint
         self.ctx = Context(device)          # raises when there is no GPU / no library
+        # The first scan of a process used to page-lock its frame buffers inside the call (28-30 ms for a C3 trajectory:
+        # the whole of C5's first scene).  The blocks are locked here instead, on a helper thread, while the caller goes
+        # on to read its mesh; a scan that comes sooner simply locks what is not there yet.
+        sizes = self.PRELOCK_BYTES if prelock_bytes is None else tuple(prelock_bytes)
+        if sizes and os.environ.get("LRC_PRELOCK", "1") != "0":
+            self.ctx.pinned.reserve_async(sizes)
         self._scenes = {}                   # id(mesh) -> (weakref or None, fingerprint, Scene)
         self._dir_tables = {}
         self._grids = {}

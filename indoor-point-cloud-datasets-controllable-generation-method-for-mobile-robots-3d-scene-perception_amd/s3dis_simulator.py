@@ -216,10 +216,17 @@ class S3DISSimulator:
         # summation order (csrc/lrc_stats.h), so neither the range column nor a host reduction is needed
         from lidarcast.npmodel import reductions_match
         device_stats = reductions_match()       # a numpy that sums differently reduces the columns itself
-        want = ("point3", "sem", "ins", "range_origin_stats" if device_stats else "range_origin") + \
-            (() if self.bug_compatible else (("incident_deg", "incident_stats") if device_stats else ("incident_deg",)))
         batched = isinstance(self.lidar_config, Indoor8LineLidarIntrinsics) and \
             self.lidar_config.vertical_degrees is not None
+        # the hit triangles' labels are an extra of this package's frames (the reference's frame has none,
+        # containers/s3dis_sim_frame.py:90-101): by default they stay on the device side -- a second, labels-only scan of
+        # the same poses fetches them the first time a frame's labels are looked at (or at export) -- so that a caller who
+        # never does is not made to wait for four of every sixteen bytes to cross PCIe.  raycast_engine.eager_labels: true
+        # brings them with the points as before.
+        lazy_labels = batched and not bool(self.config.get("raycast_engine", {}).get("eager_labels", False))
+        want = ("point3",) + (() if lazy_labels else ("sem", "ins")) + \
+            ("range_origin_stats" if device_stats else "range_origin",) + \
+            (() if self.bug_compatible else (("incident_deg", "incident_stats") if device_stats else ("incident_deg",)))
         device_gen = bool(self.config.get("raycast_engine", {}).get("device_ray_generation", False))
         fr = None
         from lidarcast.distributed import active_group, scan_frames_sharded, scan_lidars_sharded
@@ -266,8 +273,14 @@ class S3DISSimulator:
                 fr["incident_deg"] = np.zeros(fr["total"])
             counts_l = fr["counts"].tolist()
             ends_l = list(itertools.accumulate(counts_l))
-            pts_f, sem_f, ins_f, ang_f = ([fr[a][e - c:e] for c, e in zip(counts_l, ends_l)]
-                                          for a in ("point3", "sem", "ins", "incident_deg"))
+            pts_f, ang_f = ([fr[a][e - c:e] for c, e in zip(counts_l, ends_l)] for a in ("point3", "incident_deg"))
+            if "sem" in fr:
+                sem_f, ins_f = ([fr[a][e - c:e] for c, e in zip(counts_l, ends_l)] for a in ("sem", "ins"))
+                src_f = itertools.repeat(None)
+            else:      # labels on demand: one labels-only scan of the trajectory, shared by its frames
+                sem_f = ins_f = itertools.repeat(None)
+                src_f = itertools.repeat(_LazyTrajectoryLabels(engine, self.lidar_config, poses_from_waypoints(waypoints),
+                                                               mesh, counts_l))
             if "range_origin_mean" in fr:      # statistics from the device
                 qual = self._quality_from_stats(fr, total, volume)
             else:
@@ -276,7 +289,7 @@ class S3DISSimulator:
                 qual = self._quality_many(pts_f, ang_f, total, volume, engine.split_frames(fr, "range_origin"))
         if fr is not None:
             sim_scene.frames.extend(map(S3DISSimFrame, range(len(waypoints)), pts_f, ang_f, qual, itertools.repeat(None),
-                                        sem_f, ins_f))
+                                        sem_f, ins_f, src_f))
         for i, wp in enumerate(waypoints if fr is None else ()):
             a, b = off[i], off[i + 1]
             keep = seg["t"][a:b] != np.inf
@@ -289,6 +302,31 @@ class S3DISSimulator:
                                                  instance_labels=ins))
         sim_scene.compute_statistics(time.time() - start)
         return sim_scene
+
+
+class _LazyTrajectoryLabels:
+    """The hit triangles' labels of a scanned trajectory, fetched when a frame is first asked for them: one labels-only scan
+    of the same poses over the same mesh (the scan is a pure function of both: same kept rays, same order), whose result
+    all frames of the trajectory share."""
+
+    def __init__(self, engine, intrinsics, poses, mesh, counts):
+        self._args = (engine, intrinsics, np.array(poses, dtype=np.float64, copy=True), mesh)
+        self._counts = list(counts)
+        self._sem = self._ins = None
+        import threading
+        self._lock = threading.Lock()
+
+    def frame_labels(self, i):
+        with self._lock:
+            if self._sem is None:
+                engine, intrinsics, poses, mesh = self._args
+                fr = engine.scan_frames(intrinsics, poses, mesh, want=("sem", "ins"))
+                if fr["counts"].tolist() != self._counts:
+                    raise RuntimeError("the mesh or the scan options changed between the scan and the first look at its labels")
+                self._sem, self._ins, self._ends = fr["sem"], fr["ins"], list(itertools.accumulate(self._counts))
+                self._args = None
+        e, c = self._ends[i], self._counts[i]
+        return self._sem[e - c:e], self._ins[e - c:e]
 
 
 def load_config(config_path: str) -> Dict[str, Any]:

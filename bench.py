@@ -357,24 +357,104 @@ def main():
     io.tile_count = hits["tile_count"].data_ptr()
     io.counts, io.out_xyzl = counts.data_ptr(), cloud.data_ptr()
     stream = torch.cuda.current_stream().cuda_stream
-    own_prim, own_tile_count = hits.struct.prim, hits.struct.tile_count
     if dist_path:
-        # N > 1: every rank scans its own poses, ONE all-gather per scan moves the 4-byte triangle id of every ray
-        # and the per-wave keep counts (the trace kernel writes both straight into the send slab), and every rank
-        # rebuilds the whole cloud from the gathered ids (t recomputed with the scan's own ray/triangle test).
-        # Two buffer sets: the collective of scan i overlaps the trace of scan i+1.
-        from lidarcast.distributed import PrimGather
-        gathers = [PrimGather(P, N, dist, dev, world=job) for _ in range(2)]
         all_poses = np.concatenate([c3_poses(r, job) for r in range(job)]).reshape(P * job, 16)
         d_all_poses = torch.from_numpy(all_poses).to(dev)
-        for g in gathers:                         # virtual ranks: their slabs are filled once, outside the timing
-            for v in range(1, job if world == 1 else 1):
-                hits.struct.prim = g.all_slabs[v * g.words:].data_ptr()
-                hits.struct.tile_count = g.all_slabs[v * g.words + g.n:].data_ptr()
-                scene.scan_poses_dev(d_all_poses[v * P:(v + 1) * P], d_dirs, hits, sensor.max_range, stream)
-        torch.cuda.synchronize()
-    else:
-        gathers = None
+    own_slab = rank if world > 1 else 0
+
+    def make_dist(payload):
+        """The N-rank step for one of the three payloads the package offers (lidarcast.distributed); every one = trace of the
+        rank's own poses + ONE all-gather per scan (double buffered: the collective of scan i overlaps the trace of scan
+        i+1) + assembly of the whole scene cloud on every GPU:
+          prim   4 B per ray: the hit triangle's row (+ per-wave keep counts); the other ranks' rows are rebuilt from the ids
+                 (t recomputed with the scan's own ray / triangle test), the own rows scattered from the local records
+          range  8 B per ray: (t, label) pairs; every rank rebuilds all rows as o + d * t -- no plane gathers
+          rows   16 B per kept ray: locally compacted rows; nothing to rebuild (the close-up copy of the slabs into one
+                 array is NOT in this step: a lower bound)
+        Returns (step, drain, name)."""
+        from lidarcast.distributed import CloudGather, PrimGather, RangeGather
+        st_ = {"i": 0, "pending": None}
+        side = torch.cuda.Stream(device=dev)
+        rebuilt = [None, None]                   # event: the assembly that last READ gathers[k]'s receive buffer is done
+        if payload == "prim":
+            gathers = [PrimGather(P, N, dist, dev, world=job) for _ in range(2)]
+        elif payload == "range":
+            gathers = [RangeGather(n, dist, dev, world=job) for _ in range(2)]
+        else:
+            gathers = [CloudGather(n, P, dist, dev, world=job) for _ in range(2)]
+        own_ios = []
+        for h in hits_sets:                      # the rank's own records, as the own-row scatter of the rebuild reads them
+            o = LrcCompactIO()
+            o.t, o.point3, o.sem, o.ins = h["t"].data_ptr(), h["point3"].data_ptr(), h["sem"].data_ptr(), h["ins"].data_ptr()
+            own_ios.append(o)
+        if world == 1 and job > 1 and payload != "rows":
+            # virtual ranks (single-GPU diagnostics): their slabs are filled once, outside the timing
+            tl = lidarcast.DeviceHits(0, dev, want=())
+            for g in gathers:
+                for v in range(1, job):
+                    if payload == "prim":
+                        tl.struct.prim = g.all_slabs[v * g.words:].data_ptr()
+                        tl.struct.tile_count = g.all_slabs[v * g.words + g.n:].data_ptr()
+                    else:
+                        tl.struct.t_label = g.all_pairs[v * n:].data_ptr()
+                    scene.scan_poses_dev(d_all_poses[v * P:(v + 1) * P], d_dirs, tl, sensor.max_range, stream)
+            torch.cuda.synchronize()
+
+        def assemble(k):
+            g = gathers[k]
+            with torch.cuda.stream(side):
+                g.work.wait()                    # the side stream waits for the collective of that scan
+                if payload == "prim":
+                    scene.cloud_from_prims_dev(d_all_poses, d_dirs, g.all_prims, cloud, counts, g.all_tile_counts,
+                                               poses_per_slab=P, slab_stride_bytes=g.stride_bytes, stream=side.cuda_stream,
+                                               own_slab=own_slab, own_io=own_ios[k])
+                elif payload == "range":
+                    ctx.cloud_from_ranges_dev(d_all_poses, d_dirs, g.all_pairs, cloud, counts, side.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            rebuilt[k] = ev
+
+        def step(timed):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            k = st_["i"] % 2
+            st_["i"] += 1
+            g = gathers[k]
+            main = torch.cuda.current_stream()
+            if g.work is not None:
+                g.work.wait()                    # the collective that last read this send slab (scan i-2) is done
+            if rebuilt[k] is not None:
+                main.wait_event(rebuilt[k])      # ... and so is the assembly that read its receive buffer
+            hk = hits_sets[k]
+            if payload == "prim":                # the 36-byte record is complete; its id column IS the send slab
+                hk.struct.prim, hk.struct.tile_count = g.prim.data_ptr(), g.tile_count.data_ptr()
+            elif payload == "range":
+                hk.struct.t_label = g.slab.data_ptr()
+            scene.scan_poses_dev(d_poses, d_dirs, hk, sensor.max_range, stream)
+            if timed:
+                e1.record()
+                k_events.append((e0, e1))
+            if payload == "rows":                # compacted straight into the send slab, per-pose counts in its tail
+                o = LrcCompactIO()
+                o.t, o.point3, o.sem, o.ins = hk["t"].data_ptr(), hk["point3"].data_ptr(), hk["sem"].data_ptr(), hk["ins"].data_ptr()
+                o.tile_count, o.counts, o.out_xyzl = hk["tile_count"].data_ptr(), g.counts.data_ptr(), g.slab.data_ptr()
+                ctx.compact_dev(P, N, o, stream)
+            g.gather(async_op=True)              # ONE RCCL all-gather per scan, ordered after the trace
+            if st_["pending"] is not None:
+                assemble(st_["pending"])         # cloud of the previous scan: other stream, beside the next trace
+            st_["pending"] = k
+
+        def drain():
+            if st_["pending"] is not None:
+                assemble(st_["pending"])
+                st_["pending"] = None
+            torch.cuda.current_stream().wait_stream(side)
+            for h in hits_sets:                  # leave the record sets as they were found
+                h.struct.prim, h.struct.tile_count = h["prim"].data_ptr(), h["tile_count"].data_ptr()
+                h.struct.t_label = None
+
+        return step, drain
 
     # N = 1 (default): the library's scan pipeline; its rows go to three rotating output buffers (a submit's rows are written
     # up to two submits later).  The bytes are checked against the two-call step below, in this run.
@@ -385,79 +465,64 @@ def main():
         pipe_counts = [counts] + [torch.zeros_like(counts) for _ in range(2)]
 
     k_events = []
-    state = {"i": 0, "pending": None}
-    if gathers is not None:
-        # The rebuild of scan i-1 goes to a second stream, next to the trace of scan i+1 and the collective of scan i.
-        # (Measured with buffers sized for 8 ranks: two streams 0.675 ms per step, one stream 0.730, the rebuild folded
-        # into the trace launch as a per-wave tail 0.717 -- both kernels load the vector L1 path, so what overlap
-        # there is comes from the launch gaps and the tails of the two grids.)
-        side = torch.cuda.Stream(device=dev)
-        rebuilt = [None, None]                   # event: the rebuild that last READ gathers[k].all_slabs is done
-
-    own_ios = []
-    for h in hits_sets:                          # the rank's own records, as the own-row scatter of the rebuild reads them
-        o = LrcCompactIO()
-        o.t, o.point3, o.sem, o.ins = h["t"].data_ptr(), h["point3"].data_ptr(), h["sem"].data_ptr(), h["ins"].data_ptr()
-        own_ios.append(o)
-    own_slab = rank if world > 1 else 0
-
-    def rebuild(k):
-        g = gathers[k]
-        with torch.cuda.stream(side):
-            g.work.wait()                        # the side stream waits for the collective of that scan
-            # the other ranks' rows are rebuilt from their triangle ids; this rank's own rows come straight from the
-            # records its trace wrote (lrc_cloud_from_prims_own_dev): nothing is computed twice
-            scene.cloud_from_prims_dev(d_all_poses, d_dirs, g.all_prims, cloud, counts, g.all_tile_counts,
-                                       poses_per_slab=P, slab_stride_bytes=g.stride_bytes, stream=side.cuda_stream,
-                                       own_slab=own_slab, own_io=own_ios[k])
-            ev = torch.cuda.Event()
-            ev.record(side)
-        rebuilt[k] = ev
+    state = {"i": 0}
+    dist_payload, dist_calibration = None, None
+    if dist_path:
+        # Which payload is fastest depends on the link (xGMI all-gather against the rebuild it saves), which only the
+        # hardware can say: a few warm steps of each, the fastest runs the timed blocks, all three go into the report.
+        def probe(payload, steps=12):
+            stp, drn = make_dist(payload)
+            for _ in range(3):
+                stp(False)
+            drn()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                stp(False)
+            drn()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            if world > 1:
+                tm = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                dt = float(tm.item())
+            return dt * 1e3
+        forced = os.environ.get("LRC_DIST_PAYLOAD")
+        if forced:
+            dist_payload = forced
+        else:
+            dist_calibration = {pl: probe(pl) for pl in ("prim", "range", "rows")}
+            # "rows" leaves the close-up copy out, so it must win by more than that copy could cost to be chosen
+            dist_payload = min(("prim", "range"), key=lambda pl: dist_calibration[pl])
+        dist_step, dist_drain = make_dist(dist_payload)
 
     def step(timed):
-        if timed and not use_pipe:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         if use_pipe:
             j = state["i"] % 3
             state["i"] += 1
             pipe.submit(d_poses, d_dirs, sensor.max_range, out_rows_t=pipe_rows[j], counts_t=pipe_counts[j], stream=stream)
             return
-        if gathers is None:
-            scene.scan_poses_dev(d_poses, d_dirs, hits, sensor.max_range, stream)
-            if timed:
-                e1.record()
-                k_events.append((e0, e1))
-            ctx.compact_dev(P, N, io, stream)
+        if dist_path:
+            dist_step(timed)
             return
-        k = state["i"] % 2
-        state["i"] += 1
-        g = gathers[k]
-        main = torch.cuda.current_stream()
-        if g.work is not None:
-            g.work.wait()                        # the collective that last read this send slab (scan i-2) is done
-        if rebuilt[k] is not None:
-            main.wait_event(rebuilt[k])          # ... and so is the rebuild that read its receive buffer
-        hk = hits_sets[k]
-        hk.struct.prim = g.prim.data_ptr()       # the 36-byte record is complete; its id column IS the send slab
-        hk.struct.tile_count = g.tile_count.data_ptr()
-        scene.scan_poses_dev(d_poses, d_dirs, hk, sensor.max_range, stream)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        scene.scan_poses_dev(d_poses, d_dirs, hits, sensor.max_range, stream)
         if timed:
             e1.record()
             k_events.append((e0, e1))
-        g.gather(async_op=True)                  # ONE RCCL all-gather per scan, ordered after the trace
-        if state["pending"] is not None:
-            rebuild(state["pending"])            # cloud of the previous scan: other stream, overlaps the next trace
-        state["pending"] = k
+        ctx.compact_dev(P, N, io, stream)
 
     def drain():
         if use_pipe:
             pipe.wait(stream)          # scatters the rows still in the pipeline, orders this stream behind everything
-        if gathers is not None:
-            if state["pending"] is not None:
-                rebuild(state["pending"])
-                state["pending"] = None
-            torch.cuda.current_stream().wait_stream(side)
+        if dist_path:
+            dist_drain()
 
     def barrier():
         drain()
@@ -532,12 +597,11 @@ def main():
             assert torch.equal(r_[:kk].view(torch.int32), serial_rows[:kk].view(torch.int32)), \
                 "scan pipeline: rows differ from the two-call step"
 
-    if args.dist_selftest:
-        # the cloud rebuilt from the gathered triangle ids must equal the local compaction, bit for bit
+    if args.dist_selftest and dist_payload != "rows":
+        # the cloud rebuilt from the gathered triangle ids / (t, label) pairs must equal the local compaction, bit for bit
         k = int(counts.sum().item())
         rebuilt = cloud[:k].clone()
         rebuilt_counts = counts.clone()
-        hits.struct.prim, hits.struct.tile_count = own_prim, own_tile_count
         local = torch.empty((n, 4), dtype=torch.float32, device=dev)
         local_counts = torch.zeros(P, dtype=torch.int64, device=dev)
         io.out_xyzl, io.counts = local.data_ptr(), local_counts.data_ptr()
@@ -552,8 +616,8 @@ def main():
                 f"rebuilt cloud differs in the poses of rank {v}"
             row += kv
         assert row == k, "row totals differ"
-        print(f"dist selftest ok: {k} rows rebuilt from gathered triangle ids == local compaction, "
-              f"world {world}, buffers sized for {job} ranks", file=sys.stderr)
+        print(f"dist selftest ok: {k} rows rebuilt from the gathered '{dist_payload}' payload == local compaction, "
+              f"world {world}, buffers sized for {job} ranks; calibration {dist_calibration}", file=sys.stderr)
     kernel_ms = float(np.median([a.elapsed_time(b) for a, b in k_events]))
     hits_total = int(counts.sum().item())
     bpr = bytes_per_ray(info["num_triangles"])
@@ -658,6 +722,12 @@ def main():
                                      if use_pipe else
                                      ("two calls on one stream: lrc_scan_poses_dev + lrc_compact_dev (--serial)" if not dist_path
                                       else "one process per GPU: trace + all-gather + cloud assembly, double buffered")),
+                **({"gather_payload": dist_payload,
+                    "gather_payload_calibration_ms_per_step": dist_calibration,
+                    "gather_payload_note": "prim = 4 B triangle id per ray + rebuild of the other ranks' rows; range = 8 B "
+                                           "(t, label) per ray + rebuild of all rows without plane gathers; rows = 16 B per kept "
+                                           "ray, nothing rebuilt, close-up copy NOT included (lower bound); a dozen warm steps each "
+                                           "at start-up, the faster of prim / range runs the timed blocks"} if dist_path else {}),
                 **({"serial_ms_per_step": serial_ms,
                     "serial_note": "the same step as lrc_scan_poses_dev + lrc_compact_dev on one stream, same box, same run "
                                    "(median of 12 blocks); roofline.kernel_ms is the trace launch of THESE steps, alone on the "

@@ -1469,6 +1469,7 @@ void build_options_from_env(lrc::BuildOptions& opt) {
     opt.bfs_nodes = env_int("LRC_BFS_NODES", opt.bfs_nodes);
     opt.depth_slack = env_int("LRC_DEPTH_SLACK", opt.depth_slack);
     opt.median_only = env_int("LRC_BUILD_MEDIAN_ONLY", 0);      // test hook: every split takes the median fallback
+    opt.subtrees = env_int("LRC_BUILD_SUBTREES", opt.subtrees);  // 0: the device builder goes level by level to the bottom (A/B)
 }
 
 // LRC_QNODES: 0 = float32 nodes only, 1 (default) = quantised images when the grid is fine enough for the scene's

@@ -37,6 +37,8 @@ struct BuildOptions {
     int threads   = 0;          // 0 = min(hardware threads, 16)
     int depth_slack = 2;        // >= 0: leaf depth <= balanced-tree height + slack; -1: only the hard cap (31)
     int median_only = 0;        // test hook: every split is the median fallback (exercises that path in both builders)
+    int subtrees = 1;           // device builder: nodes of <= 64 primitives beyond the breadth-first head are finished by one
+                                // wave each in ONE launch (k_subtree) instead of level by level; 0 = level by level throughout
 };
 
 // verts3: V x 3 float32, tris3: T x 3 uint32 (validated by the caller).  Deterministic.

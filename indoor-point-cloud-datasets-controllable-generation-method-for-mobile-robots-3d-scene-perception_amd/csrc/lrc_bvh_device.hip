@@ -78,7 +78,7 @@ struct BigWork {                     // one per big node of the current level
     uint32_t pad[4];
 };
 
-struct LevelCounters { uint32_t n_nodes, n_small, n_medium, n_big, n_leaves, max_leaf, n_median, error, n_tiny, pad[3]; };
+struct LevelCounters { uint32_t n_nodes, n_small, n_medium, n_big, n_leaves, max_leaf, n_median, error, n_tiny, n_sub, pad[2]; };
 
 struct Params {
     const PrimRec* cur;
@@ -340,6 +340,232 @@ __global__ __launch_bounds__(256) void k_small(const Params P, const uint32_t* l
         nd.mid = begin + nL;
 #pragma unroll
         for (int k = 0; k < 6; ++k) { nd.box[0][k] = lbox[k]; nd.box[1][k] = rbox[k]; }
+    }
+}
+
+// ---- whole subtrees of <= 64 primitives: one wave each (round 4) ------------------------------------------------------------
+// Below a node of <= 64 primitives nothing needs the grid any more: the wave that holds its primitives (one per lane) splits
+// it, keeps both halves in its lanes and goes on, node after node from a small stack in LDS, with k_small's arithmetic for
+// every node (bins of the three axes in LDS, bin per lane, costs in double, first minimum; the median fallback by rank) --
+// so the tree below such a node is the tree the level-by-level kernels built, and with it every byte of the scene.  What
+// it saves is the grid: the last six to eight levels of a 10^6-triangle mesh (two to four launches and a counter read-back
+// each) become ONE launch.  Descendants are staged at stage[first primitive + j] (an inner node per split position at most, so
+// a root's nodes fit its own primitive range) with wave-local child numbers; k_sub_scan turns the per-root counts into node
+// numbers behind the level-numbered nodes and k_sub_place moves them there.  Only nodes numbered beyond the breadth-first
+// head of the final layout are built this way (the head keeps its breadth-first numbers; the tail is laid out by
+// (first primitive, depth), whatever its numbers were).
+struct SNode { uint32_t begin, end, mid, depth; int32_t child[2]; int32_t box[2][6]; uint32_t pad[2]; };
+static_assert(sizeof(SNode) == 80, "SNode layout");
+struct SubRoot { uint32_t g, parity; };              // node number of the subtree's root, buffer its primitives lie in
+struct SubInfo { uint32_t count, leaves, max_leaf, max_depth; };     // per root: staged nodes, leaves, largest leaf, deepest inner node + 1
+struct SubTotals { uint32_t nodes, leaves, max_leaf, max_depth; };
+
+__global__ __launch_bounds__(256) void k_subtree(const Params P, const PrimRec* buf0, const PrimRec* buf1, const SubRoot* roots,
+                                                 uint32_t n_roots, SNode* stage, SubInfo* info) {
+    __shared__ int s_bins[4][7 * kBinsN];
+    __shared__ uint4 s_stack[4][64];                  // (b, e, depth, local number)
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_roots) return;                         // whole waves leave; no workgroup barrier below
+    int* bins = s_bins[threadIdx.x >> 6];
+    uint4* stack = s_stack[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const SubRoot root = roots[w];
+    TNode& rn = P.nodes[root.g];
+    const uint32_t gbegin = rn.begin, n_root = rn.end - gbegin;
+    LoadedPrim pr{};
+    if ((uint32_t)lane < n_root) pr = load_prim((root.parity ? buf1 : buf0) + gbegin + lane);
+    uint32_t next_local = 1, leaves = 0, maxl = 0, maxd = 0;      // wave-uniform
+    int sp = 0;
+    uint32_t b = 0, e = n_root, depth = rn.depth, me = 0;
+    for (;;) {
+        const uint32_t n = e - b;
+        const bool act = (uint32_t)lane >= b && (uint32_t)lane < e;
+        int cb[6];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            cb[k] = wave_min(act ? enc(pr.c[k]) : kEncPosMax);
+            cb[3 + k] = wave_max(act ? enc(pr.c[k]) : kEncNegMax);
+        }
+        double best_cost = 1.7976931348623157e308;     // DBL_MAX, as the host starts
+        int best_axis = -1, best_bin = -1;
+        int lbox[6], rbox[6];
+        uint32_t nL = 0;
+        int mybin[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { lbox[k] = 0; rbox[k] = 0; }
+        if (!P.median_only) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const float lo = dec(cb[ax]), ext = dec(cb[3 + ax]) - lo;
+                if (!(ext > 0.0f)) continue;
+                const float scale = (float)kBinsN / ext;
+                const int bn = bin_of(pr.c[ax], lo, scale);
+                mybin[ax] = bn;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { bins[k * kBinsN + lane] = kEncPosMax; bins[(3 + k) * kBinsN + lane] = kEncNegMax; }
+                bins[6 * kBinsN + lane] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (act) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        atomicMin(&bins[k * kBinsN + bn], enc(pr.lo[k]));
+                        atomicMax(&bins[(3 + k) * kBinsN + bn], enc(pr.hi[k]));
+                    }
+                    atomicAdd(&bins[6 * kBinsN + bn], 1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                int bb[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) bb[k] = bins[k * kBinsN + lane];
+                const uint32_t bc = (uint32_t)bins[6 * kBinsN + lane];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                const AxisBest r = eval_axis(lane, bb, bc);
+                if (r.cost < best_cost) {
+                    best_cost = r.cost; best_axis = ax; best_bin = r.bin; nL = r.lcnt;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) { lbox[k] = r.lbox[k]; rbox[k] = r.rbox[k]; }
+                }
+            }
+        }
+        bool pred = false;
+        bool have_split = false;
+        if (best_axis >= 0) {
+            have_split = fits(nL, (int)depth + 1, P) && fits(n - nL, (int)depth + 1, P);
+            const int mb = best_axis == 0 ? mybin[0] : (best_axis == 1 ? mybin[1] : mybin[2]);
+            pred = mb <= best_bin;
+        }
+        if (!have_split) {
+            const int ax = median_axis(cb);
+            const float myc = ax == 0 ? pr.c[0] : (ax == 1 ? pr.c[1] : pr.c[2]);
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; ++j) {
+                const float cj = __shfl(myc, (int)(b + j), 64);
+                const uint32_t ij = __shfl(pr.id, (int)(b + j), 64);
+                rank += key_less(cj, ij, myc, pr.id) ? 1u : 0u;
+            }
+            nL = (n + 1u) / 2u;
+            pred = rank < nL;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lbox[k] = wave_min(act && pred ? enc(pr.lo[k]) : kEncPosMax);
+                lbox[3 + k] = wave_max(act && pred ? enc(pr.hi[k]) : kEncNegMax);
+                rbox[k] = wave_min(act && !pred ? enc(pr.lo[k]) : kEncPosMax);
+                rbox[3 + k] = wave_max(act && !pred ? enc(pr.hi[k]) : kEncNegMax);
+            }
+        }
+        // the two halves change lanes: lane b + rank within its side (stable, as k_small's store order)
+        const unsigned long long am = __ballot(act), lm = __ballot(act && pred);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const uint32_t pos = !act ? (uint32_t)lane
+                                  : (pred ? b + (uint32_t)__popcll(lm & below) : b + nL + (uint32_t)__popcll(am & ~lm & below));
+        {
+            const int dst = (int)pos * 4;
+#define LRC_MOVE_F(x) x = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(x)))
+            LRC_MOVE_F(pr.lo[0]); LRC_MOVE_F(pr.lo[1]); LRC_MOVE_F(pr.lo[2]);
+            LRC_MOVE_F(pr.hi[0]); LRC_MOVE_F(pr.hi[1]); LRC_MOVE_F(pr.hi[2]);
+            LRC_MOVE_F(pr.c[0]); LRC_MOVE_F(pr.c[1]); LRC_MOVE_F(pr.c[2]);
+#undef LRC_MOVE_F
+            pr.id = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)pr.id);
+        }
+        // the node's record, children numbered wave-locally (0 = the root itself, staged nodes from 1)
+        int32_t child[2];
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t cbeg = c == 0 ? b : b + nL, cend = c == 0 ? b + nL : e, m = cend - cbeg;
+            if (m > (uint32_t)P.max_leaf) {
+                child[c] = (int32_t)next_local;
+                if (lane == 0) stack[sp] = make_uint4(cbeg, cend, depth + 1u, next_local);
+                ++sp;
+                ++next_local;
+            } else {
+                child[c] = ~(int32_t)((gbegin + cbeg) * 8u + m);
+                ++leaves;
+                maxl = m > maxl ? m : maxl;
+            }
+        }
+        maxd = depth + 1u > maxd ? depth + 1u : maxd;
+        if (lane == 0) {
+            if (me == 0) {
+                rn.mid = gbegin + b + nL;
+                rn.child[0] = child[0]; rn.child[1] = child[1];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { rn.box[0][k] = lbox[k]; rn.box[1][k] = rbox[k]; }
+            } else {
+                SNode sn;
+                sn.begin = gbegin + b; sn.end = gbegin + e; sn.mid = gbegin + b + nL; sn.depth = depth;
+                sn.child[0] = child[0]; sn.child[1] = child[1];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { sn.box[0][k] = lbox[k]; sn.box[1][k] = rbox[k]; }
+                sn.pad[0] = sn.pad[1] = 0;
+                stage[gbegin + me - 1u] = sn;
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const uint4 t = stack[sp];
+        b = t.x; e = t.y; depth = t.z; me = t.w;
+    }
+    if ((uint32_t)lane < n_root) P.final_id[gbegin + lane] = pr.id;
+    if (lane == 0) info[w] = SubInfo{next_local - 1u, leaves, maxl, maxd};
+}
+
+// one workgroup: exclusive scan of the per-root node counts (bases[r]) and the totals of the subtree pass
+__global__ __launch_bounds__(1024) void k_sub_scan(const SubInfo* info, uint32_t n_roots, uint32_t* bases, SubTotals* totals) {
+    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_carry, s_leaves, s_maxl, s_maxd;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { s_carry = 0; s_leaves = 0; s_maxl = 0; s_maxd = 0; }
+    __syncthreads();
+    uint32_t lv = 0, ml = 0, md = 0;
+    for (uint32_t base = 0; base < n_roots; base += 1024) {
+        const uint32_t i = base + tid;
+        uint32_t v = 0;
+        if (i < n_roots) { const SubInfo f = info[i]; v = f.count; lv += f.leaves; ml = ml > f.max_leaf ? ml : f.max_leaf; md = md > f.max_depth ? md : f.max_depth; }
+        s_part[tid] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            const uint32_t add = tid >= off ? s_part[tid - off] : 0;
+            __syncthreads();
+            s_part[tid] += add;
+            __syncthreads();
+        }
+        const uint32_t carry = s_carry;
+        if (i < n_roots) bases[i] = carry + s_part[tid] - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + s_part[1023];
+        __syncthreads();
+    }
+    atomicAdd(&s_leaves, lv); atomicMax(&s_maxl, ml); atomicMax(&s_maxd, md);
+    __syncthreads();
+    if (tid == 0) *totals = SubTotals{s_carry, s_leaves, s_maxl, s_maxd};
+}
+
+// one wave per root: its staged nodes to their numbers first + bases[r] + j, wave-local child numbers made global
+__global__ __launch_bounds__(256) void k_sub_place(TNode* nodes, const SubRoot* roots, uint32_t n_roots, const SNode* stage,
+                                                   const SubInfo* info, const uint32_t* bases, uint32_t first) {
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_roots) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const SubRoot root = roots[w];
+    const uint32_t cnt = info[w].count, at = first + bases[w];
+    TNode& rn = nodes[root.g];
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (rn.child[c] > 0) rn.child[c] = (int32_t)(at + (uint32_t)rn.child[c] - 1u);
+    }
+    if (lane < cnt) {
+        const SNode sn = stage[rn.begin + lane];
+        TNode nd;
+        nd.begin = sn.begin; nd.end = sn.end; nd.mid = sn.mid; nd.depth = sn.depth;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) nd.child[c] = sn.child[c] > 0 ? (int32_t)(at + (uint32_t)sn.child[c] - 1u) : sn.child[c];
+        nd.work = -1; nd.cb_valid = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { nd.cb[k] = 0; nd.box[0][k] = sn.box[0][k]; nd.box[1][k] = sn.box[1][k]; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) nd.pad[k] = 0;
+        nodes[at + lane] = nd;
     }
 }
 
@@ -931,7 +1157,8 @@ __global__ __launch_bounds__(256) void k_emit_count(const TNode* nodes, uint32_t
     uint32_t cnt = 0;
     if (i < n) {
         const TNode& nd = nodes[base + i];
-        cnt = ((nd.mid - nd.begin) > (uint32_t)max_leaf ? 1u : 0u) + ((nd.end - nd.mid) > (uint32_t)max_leaf ? 1u : 0u);
+        if (nd.work != -2)       // a subtree root (k_subtree builds what is below it)
+            cnt = ((nd.mid - nd.begin) > (uint32_t)max_leaf ? 1u : 0u) + ((nd.end - nd.mid) > (uint32_t)max_leaf ? 1u : 0u);
     }
     if (cnt) atomicAdd(&s_sum, cnt);
     __syncthreads();
@@ -941,7 +1168,8 @@ __global__ __launch_bounds__(256) void k_emit_count(const TNode* nodes, uint32_t
 __global__ __launch_bounds__(256) void k_emit_write(TNode* nodes, uint32_t base, uint32_t n, uint32_t next_base,
                                                     int max_leaf, const uint32_t* partial, const BigWork* work,
                                                     uint32_t* list_tiny, uint32_t* list_small, uint32_t* list_medium,
-                                                    uint32_t* list_big, LevelCounters* next) {
+                                                    uint32_t* list_big, LevelCounters* next, int sub_mode, SubRoot* sub_roots,
+                                                    uint32_t* n_sub_total, uint32_t child_parity) {
     __shared__ uint32_t s_red[256];
     __shared__ uint32_t s_wave[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -960,8 +1188,11 @@ __global__ __launch_bounds__(256) void k_emit_write(TNode* nodes, uint32_t base,
     TNode* nd = nullptr;
     if (i < n) {
         nd = nodes + base + i;
-        nl = nd->mid - nd->begin; nr = nd->end - nd->mid;
-        cnt = (nl > (uint32_t)max_leaf ? 1u : 0u) + (nr > (uint32_t)max_leaf ? 1u : 0u);
+        if (nd->work == -2) nd = nullptr;          // a subtree root: no children here
+        else {
+            nl = nd->mid - nd->begin; nr = nd->end - nd->mid;
+            cnt = (nl > (uint32_t)max_leaf ? 1u : 0u) + (nr > (uint32_t)max_leaf ? 1u : 0u);
+        }
     }
     uint32_t incl = cnt;
 #pragma unroll
@@ -992,7 +1223,12 @@ __global__ __launch_bounds__(256) void k_emit_write(TNode* nodes, uint32_t base,
                 ch.cb_valid = 1;
                 for (int k = 0; k < 6; ++k) ch.cb[k] = work[nd->work].ccb[c][k];
             }
-            if (m <= (uint32_t)kTinyMax) list_tiny[atomicAdd(&next->n_tiny, 1u)] = g;
+            if (sub_mode && m <= (uint32_t)kSmallMax) {
+                ch.work = -2;
+                sub_roots[atomicAdd(n_sub_total, 1u)] = SubRoot{g, child_parity};
+                atomicAdd(&next->n_sub, 1u);
+            }
+            else if (m <= (uint32_t)kTinyMax) list_tiny[atomicAdd(&next->n_tiny, 1u)] = g;
             else if (m <= (uint32_t)kSmallMax) list_small[atomicAdd(&next->n_small, 1u)] = g;
             else if (m <= (uint32_t)kMediumMax) list_medium[atomicAdd(&next->n_medium, 1u)] = g;
             else list_big[atomicAdd(&next->n_big, 1u)] = g;
@@ -1208,6 +1444,7 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
         c.take<LevelCounters>(kMaxLevels + 1); c.take<int>(8);
         c.take<uint64_t>(T); c.take<uint64_t>(T); c.take<uint32_t>(T); c.take<uint32_t>(T); c.take<uint32_t>(T);
         c.take<double>((size_t)T / 256 + 2); c.take<uint32_t>((size_t)T / 256 + 2); c.take<uint32_t>(4);
+        c.take<SNode>(T); c.take<SubRoot>(list_cap); c.take<SubInfo>(list_cap); c.take<uint32_t>(list_cap); c.take<uint32_t>(8);
         need = c.off;
     }
     if (arena->cap < need) {
@@ -1253,6 +1490,11 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     double* infl_part = c.take<double>((size_t)T / 256 + 2);
     uint32_t* infl_cnt = c.take<uint32_t>((size_t)T / 256 + 2);
     uint32_t* qfail = c.take<uint32_t>(4);
+    SNode* sub_stage = c.take<SNode>(T);
+    SubRoot* sub_roots = c.take<SubRoot>(list_cap);
+    SubInfo* sub_info = c.take<SubInfo>(list_cap);
+    uint32_t* sub_bases = c.take<uint32_t>(list_cap);
+    uint32_t* sub_count = c.take<uint32_t>(8);             // [0] roots so far; [4..7] SubTotals
     {
         size_t tmp = 0;
         (void)rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)T, 0, 64, st);
@@ -1266,6 +1508,7 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     // ---- level 0 ----
     DB_HIP(hipMemsetAsync(counters, 0, sizeof(LevelCounters) * (kMaxLevels + 1), st));
     DB_HIP(hipMemsetAsync(qfail, 0, 16, st));
+    DB_HIP(hipMemsetAsync(sub_count, 0, 32, st));
     {
         TNode root{};
         root.begin = 0; root.end = T; root.mid = 0; root.depth = 0; root.work = -1; root.cb_valid = 1;
@@ -1306,6 +1549,8 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     }
     PrimRec* cur = bufA;
     PrimRec* nxt = bufB;
+    const bool sub_enabled = opt.subtrees != 0;
+    uint32_t n_sub_roots = 0;
     uint32_t base = 0, level = 0;
     uint64_t num_leaves = 0;
     uint32_t max_leaf_seen = 0;
@@ -1359,24 +1604,55 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
         if (lc.n_tiny)
             hipLaunchKernelGGL(k_tiny, dim3((lc.n_tiny + 15) / 16), dim3(256), 0, st, P, (const uint32_t*)L[3], lc.n_tiny);
         const uint32_t nblk = (lc.n_nodes + 255) / 256;
+        // Children of <= 64 primitives become subtree roots (k_subtree, one launch after the last level) once the numbers
+        // handed out lie beyond the breadth-first head of the final layout, whose numbers must stay breadth-first.
+        const int sub_mode = sub_enabled && (uint64_t)base + lc.n_nodes > (uint64_t)std::max(opt.bfs_nodes, 1) ? 1 : 0;
         hipLaunchKernelGGL(k_emit_count, dim3(nblk), dim3(256), 0, st, (const TNode*)nodes, base, lc.n_nodes, max_leaf, partial);
         hipLaunchKernelGGL(k_emit_write, dim3(nblk), dim3(256), 0, st, nodes, base, lc.n_nodes, base + lc.n_nodes, max_leaf,
-                           (const uint32_t*)partial, (const BigWork*)work, Ln[3], Ln[0], Ln[1], Ln[2], counters + level + 1);
+                           (const uint32_t*)partial, (const BigWork*)work, Ln[3], Ln[0], Ln[1], Ln[2], counters + level + 1,
+                           sub_mode, sub_roots, sub_count, (level + 1) & 1u);
         DB_HIP(hipMemcpyAsync(&land->lc, counters + level + 1, sizeof(LevelCounters), hipMemcpyDeviceToHost, st));
         DB_HIP(hipStreamSynchronize(st));
         base += lc.n_nodes;
         lc = land->lc;
         num_leaves += lc.n_leaves;
         max_leaf_seen = std::max(max_leaf_seen, lc.max_leaf);
-        if (lc.n_tiny + lc.n_small + lc.n_medium + lc.n_big != lc.n_nodes) {
+        if (lc.n_tiny + lc.n_small + lc.n_medium + lc.n_big + lc.n_sub != lc.n_nodes) {
             if (err) *err = "device BVH build: work lists do not add up";
             return LRC_ERR_INTERNAL;
         }
+        n_sub_roots += lc.n_sub;
         std::swap(cur, nxt);
         ++level;
+        if (lc.n_nodes > 0 && lc.n_sub == lc.n_nodes) {        // a level of subtree roots only: nothing left for the grid
+            base += lc.n_nodes;
+            ++level;
+            break;
+        }
     }
     DB_HIP(hipGetLastError());
-    const uint32_t nn = base;
+    uint32_t nn = base;
+    if (n_sub_roots) {
+        // everything below the subtree roots in one launch; then the staged nodes get their numbers behind the level-numbered ones
+        hipLaunchKernelGGL(k_subtree, dim3((n_sub_roots + 3) / 4), dim3(256), 0, st, P, (const PrimRec*)bufA, (const PrimRec*)bufB,
+                           (const SubRoot*)sub_roots, n_sub_roots, sub_stage, sub_info);
+        hipLaunchKernelGGL(k_sub_scan, dim3(1), dim3(1024), 0, st, (const SubInfo*)sub_info, n_sub_roots, sub_bases,
+                           (SubTotals*)(sub_count + 4));
+        hipLaunchKernelGGL(k_sub_place, dim3((n_sub_roots + 3) / 4), dim3(256), 0, st, nodes, (const SubRoot*)sub_roots, n_sub_roots,
+                           (const SNode*)sub_stage, (const SubInfo*)sub_info, (const uint32_t*)sub_bases, nn);
+        DB_HIP(hipMemcpyAsync(land->median, sub_count + 4, sizeof(SubTotals), hipMemcpyDeviceToHost, st));
+        DB_HIP(hipStreamSynchronize(st));
+        SubTotals tot;
+        std::memcpy(&tot, land->median, sizeof(tot));
+        if ((uint64_t)nn + tot.nodes > T) {
+            if (err) *err = "device BVH build: subtree bookkeeping out of range";
+            return LRC_ERR_INTERNAL;
+        }
+        nn += tot.nodes;
+        num_leaves += tot.leaves;
+        max_leaf_seen = std::max(max_leaf_seen, tot.max_leaf);
+        level = std::max(level, tot.max_depth);
+    }
     const auto t_tree = std::chrono::steady_clock::now();
 
     // ---- the scene arrays ----

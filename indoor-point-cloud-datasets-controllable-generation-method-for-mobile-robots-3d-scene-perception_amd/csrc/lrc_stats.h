@@ -154,8 +154,13 @@ __global__ __launch_bounds__(256) void segment_chunk_sums_kernel(const T* values
     T* out = partial + (start - first_row) / 8192 + seg;
     const T m = SQ ? mean[seg] : (T)0;
     for (uint64_t c = blockIdx.x - seg * kStatPar; c * 8192 < n; c += kStatPar) {
-        const uint64_t left = n - c * 8192;
-        const T sum = block_reduce_numpy<T, SQ>(values + start + c * 8192, left < 8192 ? left : 8192, m, s_leaf);
+        uint64_t len = n - c * 8192;
+        if (len > 8192) len = 8192;
+        // the length is made opaque: with the range [1, 8192] visible (and -fno-honor-nans, the library's device flag) this
+        // compiler drops the ragged chunk's result for T = double (tools/micro/stats_check.hip shows it); the one-workgroup
+        // form of round 2, whose length came straight from memory, never met the problem
+        asm volatile("" : "+s"(len));
+        const T sum = block_reduce_numpy<T, SQ>(values + start + c * 8192, len, m, s_leaf);
         if (threadIdx.x == 0) out[c] = sum;
         __syncthreads();
     }

@@ -30,20 +30,23 @@ class CloudGather:
     collective.  Every rank contributes the same fixed size because RCCL has no all-gather-v.
     """
 
-    def __init__(self, max_local, max_poses, dist, device, group=None):
+    def __init__(self, max_local, max_poses, dist, device, group=None, world=None):
         import torch
-        self.dist, self.group, self.world = dist, group, dist.get_world_size(group)
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group) if world is None else int(world)
         self.max_local, self.max_poses = int(max_local), int(max_poses)
         self.tail = (self.max_poses * 8 + 15) // 16
         self.rows = self.max_local + self.tail
         self.slab = torch.zeros((self.rows, 4), dtype=torch.float32, device=device)
         self.counts = self.slab[self.max_local:].view(-1).view(torch.int64)[:self.max_poses]
         self.all_rows = torch.empty((self.world * self.rows, 4), dtype=torch.float32, device=device)
+        # ``world`` may exceed the process group (single-GPU diagnostics): the collective fills the leading slabs
+        self.recv = self.all_rows[:dist.get_world_size(group) * self.rows]
         self.work = None
 
     def gather(self, async_op=False):
         """Enqueue the all-gather.  async_op=True returns at once; ``wait()`` before touching the buffers."""
-        self.work = self.dist.all_gather_into_tensor(self.all_rows, self.slab, group=self.group, async_op=async_op)
+        self.work = self.dist.all_gather_into_tensor(self.recv, self.slab, group=self.group, async_op=async_op)
 
     def wait(self):
         if self.work is not None:
@@ -78,15 +81,18 @@ class RangeGather:
     i.e. in global pose order because ranks own contiguous pose blocks.  One collective per scan; halves the
     bytes on the xGMI links, which is what bounds the multi-GPU job."""
 
-    def __init__(self, n_local, dist, device):
+    def __init__(self, n_local, dist, device, world=None):
         import torch
-        self.dist, self.world, self.n = dist, dist.get_world_size(), int(n_local)
+        self.dist, self.n = dist, int(n_local)
+        self.world = dist.get_world_size() if world is None else int(world)
         self.slab = torch.empty((self.n, 2), dtype=torch.int32, device=device)
         self.all_pairs = torch.empty((self.world * self.n, 2), dtype=torch.int32, device=device)
+        # ``world`` may exceed the process group (single-GPU diagnostics): the collective fills the leading slabs
+        self.recv = self.all_pairs[:dist.get_world_size() * self.n]
         self.work = None
 
     def gather(self, async_op=False):
-        self.work = self.dist.all_gather_into_tensor(self.all_pairs, self.slab, async_op=async_op)
+        self.work = self.dist.all_gather_into_tensor(self.recv, self.slab, async_op=async_op)
 
     def wait(self):
         if self.work is not None:

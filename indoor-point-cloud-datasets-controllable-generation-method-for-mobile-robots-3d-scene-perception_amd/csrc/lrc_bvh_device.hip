@@ -360,104 +360,182 @@ struct SubRoot { uint32_t g, parity; };              // node number of the subtr
 struct SubInfo { uint32_t count, leaves, max_leaf, max_depth; };     // per root: staged nodes, leaves, largest leaf, deepest inner node + 1
 struct SubTotals { uint32_t nodes, leaves, max_leaf, max_depth; };
 
+struct SubCand { double cost; int bin; int pad; };
+
+// All nodes of one depth below the root are split AT ONCE: a lane holds the primitive at its position, knows the node
+// [nb, ne) its position belongs to, and -- k_tiny's method, for segments of any length up to 64 -- evaluates ONE candidate,
+// the split after the bin its own centroid falls into, by walking its node's primitives in LDS (lanes of one node read the
+// same record: broadcast).  The host's sweep changes the partition only at occupied bins, equal partitions cost the same and
+// the first minimum wins, so the minimum over a node's candidates with ties to the lower bin is the host's choice.
 __global__ __launch_bounds__(256) void k_subtree(const Params P, const PrimRec* buf0, const PrimRec* buf1, const SubRoot* roots,
                                                  uint32_t n_roots, SNode* stage, SubInfo* info) {
-    __shared__ int s_bins[4][7 * kBinsN];
-    __shared__ uint4 s_stack[4][64];                  // (b, e, depth, local number)
+    __shared__ uint4 s_rec[4][64 * 3];                // per position: (enc lo xyz, enc hi x) (enc hi y, enc hi z, bins, row) (c xyz, flag)
+    __shared__ SubCand s_cand[4][64];
     const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_roots) return;                         // whole waves leave; no workgroup barrier below
-    int* bins = s_bins[threadIdx.x >> 6];
-    uint4* stack = s_stack[threadIdx.x >> 6];
+    uint4* rec = s_rec[threadIdx.x >> 6];
+    SubCand* cand = s_cand[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     const SubRoot root = roots[w];
     TNode& rn = P.nodes[root.g];
     const uint32_t gbegin = rn.begin, n_root = rn.end - gbegin;
     LoadedPrim pr{};
     if ((uint32_t)lane < n_root) pr = load_prim((root.parity ? buf1 : buf0) + gbegin + lane);
-    uint32_t next_local = 1, leaves = 0, maxl = 0, maxd = 0;      // wave-uniform
-    int sp = 0;
-    uint32_t b = 0, e = n_root, depth = rn.depth, me = 0;
-    for (;;) {
-        const uint32_t n = e - b;
-        const bool act = (uint32_t)lane >= b && (uint32_t)lane < e;
-        int cb[6];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            cb[k] = wave_min(act ? enc(pr.c[k]) : kEncPosMax);
-            cb[3 + k] = wave_max(act ? enc(pr.c[k]) : kEncNegMax);
+    uint32_t nb = 0, ne = n_root, nid = 0;            // the node this POSITION belongs to, its wave-local number
+    bool live = (uint32_t)lane < n_root;
+    uint32_t next_local = 1, leaves = 0, maxl = 0;    // wave-uniform
+    uint32_t depth = rn.depth;                        // all nodes split in one pass have the same depth
+    const unsigned long long below = (1ull << lane) - 1ull;
+    while (__builtin_amdgcn_ballot_w64(live)) {
+        const uint32_t n = live ? ne - nb : 0u;
+        rec[lane * 3] = make_uint4((uint32_t)enc(pr.lo[0]), (uint32_t)enc(pr.lo[1]), (uint32_t)enc(pr.lo[2]), (uint32_t)enc(pr.hi[0]));
+        rec[lane * 3 + 2] = make_uint4(__float_as_uint(pr.c[0]), __float_as_uint(pr.c[1]), __float_as_uint(pr.c[2]), 0u);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        int cb[6] = {kEncPosMax, kEncPosMax, kEncPosMax, kEncNegMax, kEncNegMax, kEncNegMax};
+        for (uint32_t t = 0; t < n; ++t) {
+            const uint4 c = rec[(nb + t) * 3 + 2];
+            const int e0 = enc(__uint_as_float(c.x)), e1 = enc(__uint_as_float(c.y)), e2 = enc(__uint_as_float(c.z));
+            cb[0] = imin(cb[0], e0); cb[1] = imin(cb[1], e1); cb[2] = imin(cb[2], e2);
+            cb[3] = imax(cb[3], e0); cb[4] = imax(cb[4], e1); cb[5] = imax(cb[5], e2);
         }
+        int mybin[3] = {0, 0, 0};
+        bool ok3[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const float lo = dec(cb[ax]), ext = dec(cb[3 + ax]) - lo;
+            ok3[ax] = live && (ext > 0.0f) && !P.median_only;
+            mybin[ax] = ok3[ax] ? bin_of(pr.c[ax], lo, (float)kBinsN / ext) : 0;
+        }
+        rec[lane * 3 + 1] = make_uint4((uint32_t)enc(pr.hi[1]), (uint32_t)enc(pr.hi[2]),
+                                       (uint32_t)mybin[0] | ((uint32_t)mybin[1] << 8) | ((uint32_t)mybin[2] << 16), pr.id);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         double best_cost = 1.7976931348623157e308;     // DBL_MAX, as the host starts
         int best_axis = -1, best_bin = -1;
         int lbox[6], rbox[6];
         uint32_t nL = 0;
-        int mybin[3] = {0, 0, 0};
 #pragma unroll
         for (int k = 0; k < 6; ++k) { lbox[k] = 0; rbox[k] = 0; }
-        if (!P.median_only) {
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                const float lo = dec(cb[ax]), ext = dec(cb[3 + ax]) - lo;
-                if (!(ext > 0.0f)) continue;
-                const float scale = (float)kBinsN / ext;
-                const int bn = bin_of(pr.c[ax], lo, scale);
-                mybin[ax] = bn;
+        for (int ax = 0; ax < 3; ++ax) {
+            if (!__builtin_amdgcn_ballot_w64(ok3[ax])) continue;         // no node of this wave has an extent on this axis
+            int L[6] = {kEncPosMax, kEncPosMax, kEncPosMax, kEncNegMax, kEncNegMax, kEncNegMax};
+            int R[6] = {kEncPosMax, kEncPosMax, kEncPosMax, kEncNegMax, kEncNegMax, kEncNegMax};
+            uint32_t lc = 0, rc = 0;
+            const int bi = mybin[ax];
+            for (uint32_t t = 0; t < n; ++t) {
+                const uint4 a = rec[(nb + t) * 3], b = rec[(nb + t) * 3 + 1];
+                const int bj = (int)((b.z >> (8 * ax)) & 0xFFu);
+                const bool left = bj <= bi;
+                const int v[6] = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y};
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { bins[k * kBinsN + lane] = kEncPosMax; bins[(3 + k) * kBinsN + lane] = kEncNegMax; }
-                bins[6 * kBinsN + lane] = 0;
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                if (act) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        atomicMin(&bins[k * kBinsN + bn], enc(pr.lo[k]));
-                        atomicMax(&bins[(3 + k) * kBinsN + bn], enc(pr.hi[k]));
-                    }
-                    atomicAdd(&bins[6 * kBinsN + bn], 1);
+                for (int k = 0; k < 6; ++k) {
+                    const int cl = k < 3 ? imin(L[k], v[k]) : imax(L[k], v[k]), cr = k < 3 ? imin(R[k], v[k]) : imax(R[k], v[k]);
+                    L[k] = left ? cl : L[k];
+                    R[k] = left ? R[k] : cr;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                int bb[6];
+                lc += left ? 1u : 0u;
+                rc += left ? 0u : 1u;
+            }
+            double c = __builtin_inf();
+            if (ok3[ax] && lc > 0u && rc > 0u) c = half_area(L) * (double)lc + half_area(R) * (double)rc;
+            // the node's best candidate: minimum cost, ties to the lower bin (equal bins are the same partition)
+            cand[lane] = SubCand{c, bi, 0};
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            double c2 = __builtin_inf();
+            int bb = 0x7FFFFFFF, src = lane;
+            for (uint32_t t = 0; t < n; ++t) {
+                const SubCand q = cand[nb + t];
+                if (q.cost < c2 || (q.cost == c2 && q.bin < bb)) { c2 = q.cost; bb = q.bin; src = (int)(nb + t); }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            int wl[6], wr[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) bb[k] = bins[k * kBinsN + lane];
-                const uint32_t bc = (uint32_t)bins[6 * kBinsN + lane];
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                const AxisBest r = eval_axis(lane, bb, bc);
-                if (r.cost < best_cost) {
-                    best_cost = r.cost; best_axis = ax; best_bin = r.bin; nL = r.lcnt;
+            for (int k = 0; k < 6; ++k) { wl[k] = __shfl(L[k], src, 64); wr[k] = __shfl(R[k], src, 64); }
+            const uint32_t wlc = __shfl(lc, src, 64);
+            if (c2 < best_cost) {
+                best_cost = c2; best_axis = ax; best_bin = bb; nL = wlc;
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) { lbox[k] = r.lbox[k]; rbox[k] = r.rbox[k]; }
-                }
+                for (int k = 0; k < 6; ++k) { lbox[k] = wl[k]; rbox[k] = wr[k]; }
             }
         }
-        bool pred = false;
-        bool have_split = false;
+        bool pred = false, have_split = false;
         if (best_axis >= 0) {
             have_split = fits(nL, (int)depth + 1, P) && fits(n - nL, (int)depth + 1, P);
             const int mb = best_axis == 0 ? mybin[0] : (best_axis == 1 ? mybin[1] : mybin[2]);
             pred = mb <= best_bin;
         }
-        if (!have_split) {
+        const bool need_median = live && !have_split;
+        if (__builtin_amdgcn_ballot_w64(need_median)) {       // some node of the wave takes the median fallback
             const int ax = median_axis(cb);
             const float myc = ax == 0 ? pr.c[0] : (ax == 1 ? pr.c[1] : pr.c[2]);
             uint32_t rank = 0;
-            for (uint32_t j = 0; j < n; ++j) {
-                const float cj = __shfl(myc, (int)(b + j), 64);
-                const uint32_t ij = __shfl(pr.id, (int)(b + j), 64);
+            for (uint32_t t = 0; t < n; ++t) {
+                const uint4 c = rec[(nb + t) * 3 + 2];
+                const float cj = __uint_as_float(ax == 0 ? c.x : (ax == 1 ? c.y : c.z));
+                const uint32_t ij = rec[(nb + t) * 3 + 1].w;
                 rank += key_less(cj, ij, myc, pr.id) ? 1u : 0u;
             }
-            nL = (n + 1u) / 2u;
-            pred = rank < nL;
+            const uint32_t half = (n + 1u) / 2u;
+            const bool mp = rank < half;
+            rec[lane * 3 + 2].w = mp ? 1u : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            int ml[6] = {kEncPosMax, kEncPosMax, kEncPosMax, kEncNegMax, kEncNegMax, kEncNegMax};
+            int mr[6] = {kEncPosMax, kEncPosMax, kEncPosMax, kEncNegMax, kEncNegMax, kEncNegMax};
+            for (uint32_t t = 0; t < n; ++t) {
+                const uint4 a = rec[(nb + t) * 3], b = rec[(nb + t) * 3 + 1];
+                const bool left = rec[(nb + t) * 3 + 2].w != 0u;
+                const int v[6] = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                lbox[k] = wave_min(act && pred ? enc(pr.lo[k]) : kEncPosMax);
-                lbox[3 + k] = wave_max(act && pred ? enc(pr.hi[k]) : kEncNegMax);
-                rbox[k] = wave_min(act && !pred ? enc(pr.lo[k]) : kEncPosMax);
-                rbox[3 + k] = wave_max(act && !pred ? enc(pr.hi[k]) : kEncNegMax);
+                for (int k = 0; k < 6; ++k) {
+                    const int cl = k < 3 ? imin(ml[k], v[k]) : imax(ml[k], v[k]), cr = k < 3 ? imin(mr[k], v[k]) : imax(mr[k], v[k]);
+                    ml[k] = left ? cl : ml[k];
+                    mr[k] = left ? mr[k] : cr;
+                }
+            }
+            if (need_median) {
+                nL = half; pred = mp;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { lbox[k] = ml[k]; rbox[k] = mr[k]; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+        // children: numbers for the inner ones (in position order over the wave's nodes), records written by each node's first lane
+        const uint32_t lsz = nL, rsz = n - nL;
+        const bool leader = live && (uint32_t)lane == nb;
+        const bool linner = lsz > (uint32_t)P.max_leaf, rinner = rsz > (uint32_t)P.max_leaf;
+        const unsigned long long mL = __builtin_amdgcn_ballot_w64(leader && linner), mR = __builtin_amdgcn_ballot_w64(leader && rinner);
+        const uint32_t id_left = next_local + (uint32_t)__popcll(mL & below) + (uint32_t)__popcll(mR & below);
+        const uint32_t id_right = id_left + (linner ? 1u : 0u);
+        if (leader) {
+            int32_t child[2];
+            child[0] = linner ? (int32_t)id_left : ~(int32_t)((gbegin + nb) * 8u + lsz);
+            child[1] = rinner ? (int32_t)id_right : ~(int32_t)((gbegin + nb + nL) * 8u + rsz);
+            if (nid == 0) {
+                rn.mid = gbegin + nb + nL;
+                rn.child[0] = child[0]; rn.child[1] = child[1];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { rn.box[0][k] = lbox[k]; rn.box[1][k] = rbox[k]; }
+            } else {
+                SNode sn;
+                sn.begin = gbegin + nb; sn.end = gbegin + ne; sn.mid = gbegin + nb + nL; sn.depth = depth;
+                sn.child[0] = child[0]; sn.child[1] = child[1];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { sn.box[0][k] = lbox[k]; sn.box[1][k] = rbox[k]; }
+                sn.pad[0] = sn.pad[1] = 0;
+                stage[gbegin + nid - 1u] = sn;
             }
         }
-        // the two halves change lanes: lane b + rank within its side (stable, as k_small's store order)
-        const unsigned long long am = __ballot(act), lm = __ballot(act && pred);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const uint32_t pos = !act ? (uint32_t)lane
-                                  : (pred ? b + (uint32_t)__popcll(lm & below) : b + nL + (uint32_t)__popcll(am & ~lm & below));
+        leaves += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(leader && !linner)) + (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(leader && !rinner));
+        {
+            const uint32_t lf = leader ? ((linner ? 0u : lsz) > (rinner ? 0u : rsz) ? (linner ? 0u : lsz) : (rinner ? 0u : rsz)) : 0u;
+            maxl = (uint32_t)imax((int)maxl, wave_max((int)lf));
+        }
+        next_local += (uint32_t)__popcll(mL) + (uint32_t)__popcll(mR);
+        // the two halves of every node change lanes (stable inside a side), then every POSITION learns its new node
+        const unsigned long long nm = (ne >= 64u ? ~0ull : (1ull << ne) - 1ull) & ~((1ull << nb) - 1ull);
+        const unsigned long long am = __builtin_amdgcn_ballot_w64(live), lm = __builtin_amdgcn_ballot_w64(live && pred);
+        const uint32_t pos = !live ? (uint32_t)lane
+                                   : (pred ? nb + (uint32_t)__popcll(lm & nm & below) : nb + nL + (uint32_t)__popcll(am & ~lm & nm & below));
         {
             const int dst = (int)pos * 4;
 #define LRC_MOVE_F(x) x = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(x)))
@@ -467,46 +545,16 @@ __global__ __launch_bounds__(256) void k_subtree(const Params P, const PrimRec* 
 #undef LRC_MOVE_F
             pr.id = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)pr.id);
         }
-        // the node's record, children numbered wave-locally (0 = the root itself, staged nodes from 1)
-        int32_t child[2];
-        for (int c = 0; c < 2; ++c) {
-            const uint32_t cbeg = c == 0 ? b : b + nL, cend = c == 0 ? b + nL : e, m = cend - cbeg;
-            if (m > (uint32_t)P.max_leaf) {
-                child[c] = (int32_t)next_local;
-                if (lane == 0) stack[sp] = make_uint4(cbeg, cend, depth + 1u, next_local);
-                ++sp;
-                ++next_local;
-            } else {
-                child[c] = ~(int32_t)((gbegin + cbeg) * 8u + m);
-                ++leaves;
-                maxl = m > maxl ? m : maxl;
-            }
+        const uint32_t idl = (uint32_t)__shfl((int)id_left, (int)nb, 64), idr = (uint32_t)__shfl((int)id_right, (int)nb, 64);
+        if (live) {
+            const uint32_t mid = nb + nL;
+            if ((uint32_t)lane < mid) { ne = mid; nid = idl; live = linner; }
+            else { nb = mid; nid = idr; live = rinner; }
         }
-        maxd = depth + 1u > maxd ? depth + 1u : maxd;
-        if (lane == 0) {
-            if (me == 0) {
-                rn.mid = gbegin + b + nL;
-                rn.child[0] = child[0]; rn.child[1] = child[1];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { rn.box[0][k] = lbox[k]; rn.box[1][k] = rbox[k]; }
-            } else {
-                SNode sn;
-                sn.begin = gbegin + b; sn.end = gbegin + e; sn.mid = gbegin + b + nL; sn.depth = depth;
-                sn.child[0] = child[0]; sn.child[1] = child[1];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { sn.box[0][k] = lbox[k]; sn.box[1][k] = rbox[k]; }
-                sn.pad[0] = sn.pad[1] = 0;
-                stage[gbegin + me - 1u] = sn;
-            }
-        }
-        if (sp == 0) break;
-        --sp;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        const uint4 t = stack[sp];
-        b = t.x; e = t.y; depth = t.z; me = t.w;
+        ++depth;
     }
     if ((uint32_t)lane < n_root) P.final_id[gbegin + lane] = pr.id;
-    if (lane == 0) info[w] = SubInfo{next_local - 1u, leaves, maxl, maxd};
+    if (lane == 0) info[w] = SubInfo{next_local - 1u, leaves, maxl, depth};
 }
 
 // one workgroup: exclusive scan of the per-root node counts (bases[r]) and the totals of the subtree pass

@@ -158,8 +158,7 @@ class PinnedPool:
 
     def reserve(self, sizes):
         """Page-lock blocks of these sizes NOW and put them on the free lists, so that the first trajectory's frame arrays do
-        not pay hipHostMalloc (28-30 ms for the 67 MB of a C3 trajectory) inside the caller's first scan.  Meant to be
-        called once, at engine construction, from a helper thread while the caller loads its mesh."""
+        not pay hipHostMalloc (28-30 ms for the 67 MB of a C3 trajectory) inside the caller's first scan.  Called once, at engine construction."""
         for nbytes in sizes:
             k = self._klass(max(int(nbytes), 1))
             with self._lock:
@@ -174,14 +173,6 @@ class PinnedPool:
                 self.allocations += 1
                 self._free.setdefault(k, []).append(p.value)
                 self._free_bytes += k
-
-    _reserve_thread = None
-
-    def reserve_async(self, sizes):
-        """``reserve`` on a helper thread; ``clear`` (and with it Context.close) waits for it."""
-        import threading
-        self._reserve_thread = threading.Thread(target=self.reserve, args=(tuple(sizes),), daemon=True)
-        self._reserve_thread.start()
 
     @staticmethod
     def _release(pool_ref, ptr, k, ctx):
@@ -198,9 +189,6 @@ class PinnedPool:
             ctx._lib.lrc_host_free(ctx._h, C.c_void_p(ptr))
 
     def clear(self):
-        t, self._reserve_thread = self._reserve_thread, None
-        if t is not None:
-            t.join()
         with self._lock:
             self._slab = None
             lists = list(self._free.values())

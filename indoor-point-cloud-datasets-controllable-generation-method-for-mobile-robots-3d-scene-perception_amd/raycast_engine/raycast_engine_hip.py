@@ -158,11 +158,12 @@ class RaycastEngineHIP(RaycastEngineBase):
         self.cache_check = cache_check      # "sampled" | "full": see _fingerprint
         self.ctx = Context(device)          # raises when there is no GPU / no library
         # The first scan of a process used to page-lock its frame buffers inside the call (28-30 ms for a C3 trajectory:
-        # the whole of C5's first scene).  The blocks are locked here instead, on a helper thread, while the caller goes
-        # on to read its mesh; a scan that comes sooner simply locks what is not there yet.
+        # the whole of C5's first scene).  The blocks are locked here instead, once per engine.  (On a helper thread it
+        # raced with the caller's own first HIP calls -- torch's device initialisation failed with "No HIP GPUs are
+        # available" in one run -- and the runtime serialises host allocations with other HIP calls anyway.)
         sizes = self.PRELOCK_BYTES if prelock_bytes is None else tuple(prelock_bytes)
         if sizes and os.environ.get("LRC_PRELOCK", "1") != "0":
-            self.ctx.pinned.reserve_async(sizes)
+            self.ctx.pinned.reserve(sizes)
         self._scenes = {}                   # id(mesh) -> (weakref or None, fingerprint, Scene)
         self._dir_tables = {}
         self._grids = {}

@@ -228,6 +228,13 @@ def caller_path(scene, sensor, poses, dirs, mesh, reps=7):
         ts.append(_t.perf_counter() - t0)
         del fr
     out = {"caller_path_rays_per_s": n / float(np.median(ts[2:])), "caller_path_ms": float(np.median(ts[2:])) * 1e3}
+    ts = []
+    for _ in range(reps + 2):                                   # the same call for a caller who wants the points only
+        t0 = _t.perf_counter()
+        fr = scene.scan_poses_compact(poses, table, sensor.max_range, want=("point3",))
+        ts.append(_t.perf_counter() - t0)
+        del fr
+    out["caller_path_points_only_ms"] = float(np.median(ts[2:])) * 1e3
     try:
         from raycast_engine import RaycastEngineGPU
         from s3dis_simulator import S3DISSimulator
@@ -237,13 +244,14 @@ def caller_path(scene, sensor, poses, dirs, mesh, reps=7):
         sim.load_scene(mesh, "bench")
         wps = [Waypoint(m[0, 3], m[1, 3], m[2, 3], yaw=0.0, timestamp=float(i)) for i, m in enumerate(poses)]
         ts = []
-        for _ in range(4):
+        for _ in range(9):
             t0 = _t.perf_counter()
             sc = sim.run_simulation(wps)
             ts.append(_t.perf_counter() - t0)
             del sc
-        out["run_simulation_rays_per_s"] = n / float(np.median(ts[1:]))
-        out["run_simulation_ms"] = float(np.median(ts[1:])) * 1e3
+        out["run_simulation_rays_per_s"] = n / float(np.median(ts[2:]))
+        out["run_simulation_ms"] = float(np.median(ts[2:])) * 1e3
+        out["run_simulation_ms_min"] = float(np.min(ts[2:])) * 1e3
         sim.raycast_engine.clear_cache()
     except Exception as e:                                               # noqa: BLE001 - a diagnostic figure only
         out["run_simulation_error"] = repr(e)

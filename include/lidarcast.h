@@ -110,7 +110,7 @@ int lrc_ctx_create(int device, lrc_ctx** out_ctx);
 int lrc_ctx_destroy(lrc_ctx* ctx);
 int lrc_ctx_synchronize(lrc_ctx* ctx);
 
-/* Launch chaining (on by default where the device supports stream memory operations).
+/* Launch chaining (opt-in; available where the device supports stream memory operations).
  * The poses of a trajectory are independent (s3dis_simulator.py:254-288 carries no state from one waypoint to the
  * next), so a caller may keep two scans in flight: lrc_scan_poses_dev / lrc_scan_angles_dev / lrc_cast*_dev on two
  * streams with two record sets.  A scan launch ends in a tail -- a few long-running waves on an emptying chip -- and what
@@ -119,8 +119,10 @@ int lrc_ctx_synchronize(lrc_ctx* ctx);
  * (hipStreamWaitValue64 on a signal word the previous launch's last workgroup writes when it starts) until that launch
  * has no workgroup left to hand out, and then fills the slots its tail leaves empty.  Consecutive scans on ONE stream
  * are untouched (stream order already serialises them).  The only semantic effect is an extra ordering edge from the
- * earlier-enqueued scan to the later one; results are unaffected.  Switch it off for a caller whose other stream is
- * blocked behind work that may not finish before this stream is needed. */
+ * earlier-enqueued scan to the later one; results are unaffected.  Off by default: on MI355X the workgroup dispatcher
+ * serves one launch of one-wave workgroups at a time anyway, so two bare trace launches on two
+ * streams already overlap this way and the explicit order measured equal (tools/pipe_time.py, tools/two_in_flight.py);
+ * it is kept for callers whose streams carry other kernels between the scans. */
 int lrc_ctx_set_launch_chaining(lrc_ctx* ctx, int enabled);
 int lrc_ctx_get_launch_chaining(const lrc_ctx* ctx, int* out_enabled, int* out_supported);
 

@@ -111,7 +111,7 @@ struct lrc_ctx {
     uint64_t* chain_word = nullptr;     // hipMallocSignalMemory; NULL: not supported here, launches are never chained
     uint64_t chain_seq = 0;             // sequence number of the last chained trace launch
     hipStream_t chain_stream = nullptr; // ... and the stream it went to
-    bool chain_enabled = true;          // lrc_ctx_set_launch_chaining
+    bool chain_enabled = false;         // lrc_ctx_set_launch_chaining (opt-in: measured equal to what the dispatcher does itself)
     // *_compact entry points: kernels on one stream, the transfers of finished pose chunks on another
     hipStream_t s_compute = nullptr, s_copy = nullptr, s_stats = nullptr;
     hipEvent_t ev_chunk[8] = {}, ev_compact[8] = {};

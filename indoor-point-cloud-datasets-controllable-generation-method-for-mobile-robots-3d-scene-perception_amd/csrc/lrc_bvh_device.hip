@@ -557,35 +557,32 @@ __global__ __launch_bounds__(256) void k_subtree(const Params P, const PrimRec* 
     if (lane == 0) info[w] = SubInfo{next_local - 1u, leaves, maxl, depth};
 }
 
-// one workgroup: exclusive scan of the per-root node counts (bases[r]) and the totals of the subtree pass
+// one workgroup: exclusive scan of the per-root node counts (bases[r]) and the totals of the subtree pass.  Every thread owns
+// a contiguous run of roots: one pass for its sum, a scan of the 1024 sums (wave shuffles + 16 wave totals), one pass to write.
 __global__ __launch_bounds__(1024) void k_sub_scan(const SubInfo* info, uint32_t n_roots, uint32_t* bases, SubTotals* totals) {
-    __shared__ uint32_t s_part[1024];
-    __shared__ uint32_t s_carry, s_leaves, s_maxl, s_maxd;
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) { s_carry = 0; s_leaves = 0; s_maxl = 0; s_maxd = 0; }
+    __shared__ uint32_t s_wave[16], s_leaves, s_maxl, s_maxd;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) { s_leaves = 0; s_maxl = 0; s_maxd = 0; }
     __syncthreads();
-    uint32_t lv = 0, ml = 0, md = 0;
-    for (uint32_t base = 0; base < n_roots; base += 1024) {
-        const uint32_t i = base + tid;
-        uint32_t v = 0;
-        if (i < n_roots) { const SubInfo f = info[i]; v = f.count; lv += f.leaves; ml = ml > f.max_leaf ? ml : f.max_leaf; md = md > f.max_depth ? md : f.max_depth; }
-        s_part[tid] = v;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            const uint32_t add = tid >= off ? s_part[tid - off] : 0;
-            __syncthreads();
-            s_part[tid] += add;
-            __syncthreads();
-        }
-        const uint32_t carry = s_carry;
-        if (i < n_roots) bases[i] = carry + s_part[tid] - v;
-        __syncthreads();
-        if (tid == 1023) s_carry = carry + s_part[1023];
-        __syncthreads();
+    const uint32_t per = (n_roots + 1023u) / 1024u, first = tid * per, last = first + per < n_roots ? first + per : n_roots;
+    uint32_t sum = 0, lv = 0, ml = 0, md = 0;
+    for (uint32_t i = first; i < last; ++i) {
+        const SubInfo f = info[i];
+        sum += f.count; lv += f.leaves; ml = ml > f.max_leaf ? ml : f.max_leaf; md = md > f.max_depth ? md : f.max_depth;
     }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
     atomicAdd(&s_leaves, lv); atomicMax(&s_maxl, ml); atomicMax(&s_maxd, md);
     __syncthreads();
-    if (tid == 0) *totals = SubTotals{s_carry, s_leaves, s_maxl, s_maxd};
+    uint32_t base = incl - sum, total = 0;
+    for (uint32_t k = 0; k < 16; ++k) { if (k < wave) base += s_wave[k]; total += s_wave[k]; }
+    for (uint32_t i = first; i < last; ++i) { bases[i] = base; base += info[i].count; }
+    if (tid == 0) *totals = SubTotals{total, s_leaves, s_maxl, s_maxd};
 }
 
 // one wave per root: its staged nodes to their numbers first + bases[r] + j, wave-local child numbers made global

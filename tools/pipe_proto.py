@@ -36,8 +36,7 @@ clouds = [torch.empty((n, 4), dtype=torch.float32, device=dev) for _ in range(2)
 counts = [torch.zeros(P, dtype=torch.int64, device=dev) for _ in range(2)]
 d_poses, d_dirs = torch.from_numpy(poses.reshape(P, 16)).to(dev), torch.from_numpy(dirs).to(dev)
 ctxs = [ctx] + [lidarcast.Context(0) for _ in range(3)]          # one compaction scratch per internal stream
-if os.environ.get("PIPE_CHAIN", "1") == "0":
-    ctx.set_launch_chaining(False)
+ctx.set_launch_chaining(os.environ.get("PIPE_CHAIN", "0") == "1")       # opt-in (off by default)
 print("launch chaining (enabled, supported):", ctx.launch_chaining(), flush=True)
 
 

@@ -19,8 +19,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else bench.SCENE
 K = int(os.environ.get("PIPE_STEPS", "300"))
 mesh = synth.make_scene(name)
 ctx = lidarcast.Context(0)
-if os.environ.get("PIPE_CHAIN", "1") == "0":
-    ctx.set_launch_chaining(False)
+ctx.set_launch_chaining(os.environ.get("PIPE_CHAIN", "0") == "1")       # opt-in (off by default)
 scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
 sensor = bench.c3_sensor()
 poses = bench.c3_poses(0, 1)

@@ -9,7 +9,9 @@ PAT=${2:-trace_kernel}
 # PMC_SCENE=<scene> profiles bench.py --scene <scene>; the summary (pmc.json) is then meant for profiles/pmc_<scene>.json
 SCENE_ARGS=${PMC_SCENE:+--scene $PMC_SCENE}
 # a caller's PMC_ARGS keeps the scene too (it used to drop it silently: a summary filed under the wrong scene name)
-ARGS="${PMC_ARGS:---steps 3 --warmup 1 --no-cpu-baseline --no-caller-path} $SCENE_ARGS"
+# --serial: one un-overlapped trace launch per step (inside the scan pipeline the launches carry the previous steps' scatter
+# workgroups in front: not what the roofline prices); short timed phase, the counters are per launch
+ARGS="${PMC_ARGS:---serial --steps 3 --warmup 1 --min-seconds 0.05 --no-cpu-baseline --no-caller-path} $SCENE_ARGS"
 export PMC_ARGS="$ARGS"
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG

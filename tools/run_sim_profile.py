@@ -15,7 +15,7 @@ from s3dis_simulator import S3DISSimulator  # noqa: E402
 from trajectory import Waypoint  # noqa: E402
 
 mesh = synth.make_scene(bench.SCENE)
-sim = S3DISSimulator({"raycast_engine": {"use_gpu": True}})
+sim = S3DISSimulator({"raycast_engine": {"use_gpu": True, "eager_labels": os.environ.get("EAGER_LABELS", "0") == "1"}})
 sim.lidar_config = bench.c3_sensor()
 sim.load_scene(mesh, "bench")
 poses = bench.c3_poses(0, 1)

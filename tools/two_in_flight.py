@@ -30,8 +30,7 @@ sets = [lidarcast.DeviceHits(n, dev, want=want) for _ in range(2)]
 d_poses, d_dirs = torch.from_numpy(poses.reshape(P, 16)).to(dev), torch.from_numpy(dirs).to(dev)
 streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
 K = 200
-if os.environ.get("PIPE_CHAIN", "1") == "0":
-    ctx.set_launch_chaining(False)
+ctx.set_launch_chaining(os.environ.get("PIPE_CHAIN", "0") == "1")       # opt-in (off by default)
 print("launch chaining (enabled, supported):", ctx.launch_chaining(), flush=True)
 
 

@@ -41,10 +41,29 @@ parts = {
     "BUILD_R3": body(section("2b. The scene build on the GPU")),
     "ORACLE_R3": body(section("7. Oracle and parity")),
 }
+# wording of the re-used round-2/3 text where it would read as a current figure
+parts["BUILD_R3"] = parts["BUILD_R3"].replace(
+    "*Cost* (MI355X, `tools/build_compare.py`, `profiles/r03_build_compare.txt`; mesh in pageable host memory, steady state):",
+    "*Cost as measured in ROUND 3* (level by level to the bottom; `profiles/r03_build_compare.txt`; the current figures are in "
+    "section 1 and in the round-4 paragraph below):")
+parts["STATS_KERNEL_R2"] = parts["STATS_KERNEL_R2"].replace(
+    "One 256-thread workgroup per frame:", "Round 2's form was one 256-thread workgroup per frame (its chunk reduction is what round 4 keeps):")
+parts["STATS_KERNEL_R2"] = parts["STATS_KERNEL_R2"].replace(
+    "HBM-bound in principle (two passes over 4 B per value); it runs on\nits own stream beside the next chunk's trace and is not visible in the call time.",
+    "HBM-bound in principle (two passes over 4 B per value).")
+renumber = [("section 4.1", "appendix B"), ("§4.1", "appendix B"), ("section 2b", "section 5.4"), ("§2b", "section 5.4"),
+            ("section 4.6", "section 5.8"), ("§4.6", "section 5.8"), ("§4.5", "section 5.6"), ("section 4.5", "section 5.6"),
+            ("(§5)", "(appendix A.3)"), ("§5;", "appendix A.3;"), ("(§3)", "(section 4)"), ("§3;", "section 4;"), ("§3)", "section 4)"),
+            ("section 5)", "appendix A.3)"), ("DESIGN.md section 5", "DESIGN.md appendix A.3")]
+for k in parts:
+    for a, b in renumber:
+        parts[k] = parts[k].replace(a, b)
 for k, v in parts.items():
     front = front.replace("{{" + k + "}}", v.rstrip() + "\n")
 appendix = "\n".join([
-    "# Appendix A -- the record of rounds 1-3 (as written then; superseded figures are NOT current)\n",
+    "# Appendices -- the record of rounds 1-3, as written then\n\nSuperseded figures below are NOT current (section 1 is).  Section numbers inside the appendices are the round-3 file's: "
+    "4.1 = appendix B, 4.4 and 6 = appendix C, 5 = A.3, 2b = section 5.4, 4.5 / 4.6 = sections 5.6 / 5.8, 7 = section 7.\n",
+    "# Appendix A -- round by round\n",
     "## A.1 Round 3 against VERDICT r02, item by item\n", body(section("0a. Round 3 against VERDICT r02")),
     "## A.2 Round 2 against VERDICT r01, item by item\n", body(section("0b. Round 2 against VERDICT r01")),
     "## A.3 Measurements of rounds 2 and 3 (one box per file; boxes of the pool differ by up to 10 %)\n", body(section("5. Measurements")),

@@ -370,6 +370,68 @@ def main():
         d_all_poses = torch.from_numpy(all_poses).to(dev)
     own_slab = rank if world > 1 else 0
 
+    def make_dist_pipe():
+        """The `prim` payload through the library's scan pipeline (lrc_pipe_submit_sharded): the trace launches of consecutive
+        steps alternate between the pipeline's two streams (nothing between two launches of a stream), the trace writes ids and
+        keep counts into the send slab, the all-gather of step k runs on a communication stream behind that trace, and the
+        assembly of step k-2 -- rebuild of the other ranks' rows, scatter of the own rows -- rides in the leading workgroups of
+        the trace launch of step k instead of waiting, as kernels of its own, for a trace launch to run out of workgroups."""
+        from lidarcast.distributed import PrimGather
+        st_ = {"i": 0}
+        pipe_d = lidarcast.ScanPipe(scene, P, N)
+        gathers = [PrimGather(P, N, dist, dev, world=job) for _ in range(2)]
+        tickets = [0, 0]
+        comm = torch.cuda.Stream(device=dev)
+        if world == 1 and job > 1:                 # virtual ranks: their slabs are filled once, outside the timing
+            tl = lidarcast.DeviceHits(0, dev, want=())
+            for g in gathers:
+                for v in range(1, job):
+                    tl.struct.prim = g.all_slabs[v * g.words:].data_ptr()
+                    tl.struct.tile_count = g.all_slabs[v * g.words + g.n:].data_ptr()
+                    scene.scan_poses_dev(d_all_poses[v * P:(v + 1) * P], d_dirs, tl, sensor.max_range, stream)
+            torch.cuda.synchronize()
+
+        scanned = [None, None]                     # event: gather + scan of the slabs in gathers[k] are done
+
+        def job_of(k):
+            g = gathers[k]
+            return lidarcast.ScanPipe.gathered(d_all_poses, g.all_prims, g.all_tile_counts, P, g.stride_bytes, own_slab,
+                                               tickets[k], cloud, counts, scan_slot=k)
+
+        def step(timed):
+            k = st_["i"] % 2
+            st_["i"] += 1
+            g = gathers[k]
+            main = torch.cuda.current_stream()
+            asm = None
+            if scanned[k] is not None:
+                main.wait_event(scanned[k])      # the collective of step i-2 and the scan of its keep counts are done: its
+                asm = job_of(k)                  # send slab (this one) is free again, its assembly rides in this step's launch
+            tickets[k] = pipe_d.submit_sharded(d_poses, d_dirs, sensor.max_range, g.prim, g.tile_count, assemble=asm,
+                                               stream=main.cuda_stream)
+            pipe_d.trace_done(tickets[k], comm.cuda_stream)
+            with torch.cuda.stream(comm):
+                g.gather(async_op=True)          # ONE RCCL all-gather per scan, ordered behind this step's trace
+                g.work.wait()                    # (the communication stream waits for the collective, not the host)
+                pipe_d.scan_gathered(d_dirs, job_of(k), comm.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(comm)
+            scanned[k] = ev
+
+        def drain():
+            main = torch.cuda.current_stream()
+            order = [(st_["i"] + j) % 2 for j in range(2)]      # older first
+            for k in order:
+                if scanned[k] is not None:
+                    main.wait_event(scanned[k])
+                    pipe_d.assemble(d_dirs, job_of(k), main.cuda_stream)
+                    scanned[k] = None
+                    gathers[k].work = None
+            pipe_d.wait(main.cuda_stream)
+
+        step.pipe = pipe_d
+        return step, drain
+
     def make_dist(payload):
         """The N-rank step for one of the three payloads the package offers (lidarcast.distributed); every one = trace of the
         rank's own poses + ONE all-gather per scan (double buffered: the collective of scan i overlaps the trace of scan
@@ -381,6 +443,8 @@ def main():
                  array is NOT in this step: a lower bound)
         Returns (step, drain, name)."""
         from lidarcast.distributed import CloudGather, PrimGather, RangeGather
+        if payload == "prim_pipe":
+            return make_dist_pipe()
         st_ = {"i": 0, "pending": None}
         side = torch.cuda.Stream(device=dev)
         rebuilt = [None, None]                   # event: the assembly that last READ gathers[k]'s receive buffer is done
@@ -479,11 +543,9 @@ def main():
     if dist_path:
         # Which payload is fastest depends on the link (xGMI all-gather against the rebuild it saves), which only the
         # hardware can say: a few warm steps of each, the fastest runs the timed blocks, all three go into the report.
-        steppers = {}
-
-        def probe(payload, steps=12):
-            stp, drn = steppers[payload] = make_dist(payload)
-            for _ in range(3):
+        def probe(payload, steps=48):
+            stp, drn = make_dist(payload)
+            for _ in range(8):             # first submits pay one-time set-up (plane table, transposed direction table)
                 stp(False)
             drn()
             if world > 1:
@@ -501,18 +563,26 @@ def main():
                 tm = torch.tensor([dt], dtype=torch.float64, device=dev)
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 dt = float(tm.item())
+            # every payload is probed from the same state: its buffers go back before the next one allocates (with the earlier
+            # steppers' gigabyte of slabs still mapped the later probes ran 5-20 % slower, whichever payload came later)
+            del stp, drn
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
             return dt * 1e3
         forced = os.environ.get("LRC_DIST_PAYLOAD")
         if forced:
             dist_payload = forced
         else:
-            dist_calibration = {pl: probe(pl) for pl in ("prim", "range", "rows")}
+            # each payload twice, in one order and then in the reverse one, the better run counts: a probe's figure moves by
+            # several percent with what ran before it (profiles/r04_multigpu_virtual_world.txt), whichever payload it is
+            order = os.environ.get("LRC_DIST_PROBE_ORDER", "prim_pipe,prim,range,rows").split(",")
+            dist_calibration = {pl: probe(pl) for pl in order}
+            for pl in reversed(order):
+                dist_calibration[pl] = min(dist_calibration[pl], probe(pl))
             # "rows" leaves the close-up copy out, so it must win by more than that copy could cost to be chosen
-            dist_payload = min(("prim", "range"), key=lambda pl: dist_calibration[pl])
-        # the stepper that was calibrated runs the timed blocks (same buffers: where a slab lies in HBM moves the rebuild
-        # kernel by several percent); the others are dropped
-        dist_step, dist_drain = steppers.pop(dist_payload) if dist_payload in steppers else make_dist(dist_payload)
-        steppers.clear()
+            dist_payload = min(("prim", "prim_pipe", "range"), key=lambda pl: dist_calibration[pl])
+        dist_step, dist_drain = make_dist(dist_payload)
 
     def step(timed):
         if use_pipe:
@@ -632,6 +702,11 @@ def main():
         assert row == k, "row totals differ"
         print(f"dist selftest ok: {k} rows rebuilt from the gathered '{dist_payload}' payload == local compaction, "
               f"world {world}, buffers sized for {job} ranks; calibration {dist_calibration}", file=sys.stderr)
+    if not k_events:          # the pipelined N-rank step has no un-overlapped launch of its own: time a few here
+        io.out_xyzl, io.counts = cloud.data_ptr(), counts.data_ptr()
+        for _ in range(12):
+            serial_step(True)
+        torch.cuda.synchronize()
     kernel_ms = float(np.median([a.elapsed_time(b) for a, b in k_events]))
     hits_total = int(counts.sum().item())
     bpr = bytes_per_ray(info["num_triangles"])
@@ -738,10 +813,12 @@ def main():
                                       else "one process per GPU: trace + all-gather + cloud assembly, double buffered")),
                 **({"gather_payload": dist_payload,
                     "gather_payload_calibration_ms_per_step": dist_calibration,
-                    "gather_payload_note": "prim = 4 B triangle id per ray + rebuild of the other ranks' rows; range = 8 B "
+                    "gather_payload_note": "prim = 4 B triangle id per ray + rebuild of the other ranks' rows; prim_pipe = the same payload "
+                                           "through the library's scan pipeline (trace launches overlapped, the assembly in the "
+                                           "leading workgroups of a later trace launch); range = 8 B "
                                            "(t, label) per ray + rebuild of all rows without plane gathers; rows = 16 B per kept "
-                                           "ray, nothing rebuilt, close-up copy NOT included (lower bound); a dozen warm steps each "
-                                           "at start-up, the faster of prim / range runs the timed blocks"} if dist_path else {}),
+                                           "ray, nothing rebuilt, close-up copy NOT included (lower bound); two runs of 48 warm steps each (the better counts) "
+                                           "at start-up, the fastest of prim / prim_pipe / range runs the timed blocks"} if dist_path else {}),
                 **({"serial_ms_per_step": serial_ms,
                     "serial_note": "the same step as lrc_scan_poses_dev + lrc_compact_dev on one stream, same box, same run "
                                    "(median of 12 blocks); roofline.kernel_ms is the trace launch of THESE steps, alone on the "

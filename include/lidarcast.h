@@ -277,6 +277,43 @@ int lrc_pipe_wait(lrc_pipe* pipe, void* stream);
 int lrc_pipe_records(lrc_pipe* pipe, uint64_t ticket, lrc_hits* out_records);
 int lrc_pipe_trace_ms(lrc_pipe* pipe, uint64_t ticket, float* out_ms);
 
+/* The pipeline on N ranks (one process per GPU; the collective itself is the caller's: RCCL all-gather of the send slabs).
+ *   lrc_pipe_submit_sharded  traces this rank's pose block like lrc_pipe_submit, with the triangle ids and per-wave keep counts
+ *                            written straight into the caller's send slab (d_send_prim: P * rays_per_pose words,
+ *                            d_send_tile_count: one word per 64 rays); `assemble` (nullable) describes an EARLIER scan whose
+ *                            slabs of ALL ranks have been gathered: its assembly -- the other ranks' rows rebuilt from their
+ *                            ids (lrc_cloud_from_prims_own_dev's arithmetic, bit-identical), this rank's own rows scattered
+ *                            from the records of submit `own_ticket` -- rides in the leading workgroups of this trace launch,
+ *                            i.e. it runs when the previous launch's tail begins instead of waiting, as a separate kernel of
+ *                            4-wave workgroups does, until a trace launch has no workgroup left.  `stream` must already wait
+ *                            for the collective that produced the gathered slabs.
+ *   lrc_pipe_trace_done      `stream` waits for the trace of that submit (the send slab is complete: start the collective).
+ *   lrc_pipe_scan_gathered   the scan over the gathered keep counts of ALL ranks, to be enqueued on the communication stream
+ *                            right behind the collective (two small kernels; the launch that carries the assembly must wait for
+ *                            them through `stream` of lrc_pipe_submit_sharded).
+ *   lrc_pipe_assemble        the same assembly with the plain kernels on `stream` (the last scans of a run), after the scan.
+ * Rows and counts of an assembled scan are complete once the stream has passed lrc_pipe_wait (or lrc_pipe_assemble). */
+typedef struct lrc_gathered {
+    const double*   d_all_poses16;     /* (num_poses_all,16) the poses of ALL ranks, slab after slab                    */
+    uint64_t        num_poses_all;     /* = slabs * poses_per_slab (a rank with fewer poses pads its slab with invalid ids) */
+    const uint32_t* d_all_prims;       /* entry 0 of slab 0 of the gathered triangle ids                                 */
+    const uint32_t* d_all_tile_counts; /* entry 0 of slab 0 of the gathered per-wave keep counts                         */
+    uint64_t        poses_per_slab;
+    uint64_t        slab_stride_bytes; /* distance between slabs (ids and counts share it)                               */
+    uint64_t        own_slab;          /* this rank's slab                                                               */
+    uint64_t        own_ticket;        /* the submit that scanned it (its records must still be there: <= 3 submits ago) */
+    uint64_t        scan_slot;         /* 0 / 1: which of the pipeline's two offset tables lrc_pipe_scan_gathered fills for
+                                          this scan (alternate with the gather buffers)                                  */
+    float*          d_out_xyzl;        /* (K,4) the assembled rows, np.vstack order                                      */
+    uint64_t*       d_counts;          /* (num_poses_all) kept rays per pose, nullable                                   */
+} lrc_gathered;
+int lrc_pipe_submit_sharded(lrc_pipe* pipe, const double* d_poses16, uint64_t num_poses, const double* d_dirs3, double max_range,
+                            uint32_t* d_send_prim, uint32_t* d_send_tile_count, const lrc_gathered* assemble, void* stream,
+                            uint64_t* out_ticket);
+int lrc_pipe_trace_done(lrc_pipe* pipe, uint64_t ticket, void* stream);
+int lrc_pipe_scan_gathered(lrc_pipe* pipe, const double* d_dirs3, const lrc_gathered* gathered, void* stream);
+int lrc_pipe_assemble(lrc_pipe* pipe, const double* d_dirs3, const lrc_gathered* gathered, void* stream);
+
 /* ---- scan straight to the reference's variable-length frames ---------------------------------------
  * What S3DISSimulator.run_simulation needs from a whole trajectory (s3dis_simulator.py:254-288): per pose the kept
  * points and their attributes, in ray order.  One call = pose-batched scan (lrc_scan_poses_dev) + stable compaction

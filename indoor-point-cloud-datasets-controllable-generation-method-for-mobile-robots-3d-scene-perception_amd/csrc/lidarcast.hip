@@ -200,8 +200,16 @@ struct TraceParams {
     // wave slots the previous launch's long last waves leave empty, and are gone in microseconds; the trace tiles follow in
     // the same grid with no barrier in between.
     struct Pre {
-        uint32_t blocks;           // each takes kPreTiles tiles
+        uint32_t blocks;           // leading workgroups in all; each scatter workgroup takes kPreTiles tiles
         uint32_t rows_only;        // only the packed (x, y, z, label) rows (+ counts) are asked for: the batched form
+        // sharded form (lrc_pipe_submit_sharded): the assembly of an EARLIER scan of all ranks rides here -- the first
+        // own_blocks workgroups scatter this rank's own rows from its records at the offsets of the assembled cloud
+        // (tile_base, super_base: the scan over ALL ranks' keep counts), the others rebuild the other ranks' rows from their
+        // gathered triangle ids (rebuild_tiles, LRC_REBUILD_R tiles each; tiles of the own slab are skipped)
+        uint32_t sharded, own_blocks;
+        uint64_t tile_base;
+        const uint64_t* super_base;
+        RebuildParams rq;
         uint64_t seg_len, tps, ntiles, nseg;
         const uint32_t* tile_off;
         const uint32_t* super_total;
@@ -500,19 +508,24 @@ __device__ __forceinline__ void scatter_tile(const lrc_compact_io& io, uint64_t 
 // dividing 1024 (the tiles of a call lie in one super tile).  This is the form the trace launch of the scan pipeline runs in
 // its leading workgroups: a wave there holds a trace wave's registers and LDS, so few waves with many loads in flight each --
 // all keep flags first, then all payloads, then the stores: two memory round trips per R tiles instead of per tile.
+// super_base != NULL: the offsets are those of a scan over MORE tiles than this call's (all ranks' scans): tile t of the call is
+// tile tile_base + t of that scan and its super tile's base is tabulated (compact_base_kernel); else the bases are summed here
+// from the totals and the R tiles lie in one super tile.
 template <int R>
 __device__ __forceinline__ void scatter_tiles_xyzl(const lrc_compact_io& io, uint64_t ntiles, uint64_t tile0, uint32_t lane,
-                                                   const uint32_t* tile_off, const uint32_t* super_total) {
+                                                   const uint32_t* tile_off, const uint32_t* super_total,
+                                                   uint64_t tile_base = 0, const uint64_t* super_base = nullptr) {
     float t[R];
-    uint32_t off[R];
+    uint64_t off[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint64_t tile = tile0 + r;
         const bool valid = tile < ntiles;
         t[r] = valid ? io.t[tile * 64 + lane] : __builtin_inff();
-        off[r] = valid ? tile_off[tile] : 0u;
+        off[r] = valid ? (uint64_t)tile_off[tile_base + tile] : 0u;
+        if (super_base && valid) off[r] += super_base[(tile_base + tile) >> 10];
     }
-    const uint64_t sbase = super_prefix_wave(super_total, tile0 >> 10, lane);
+    const uint64_t sbase = super_base ? 0ull : super_prefix_wave(super_total, tile0 >> 10, lane);
     float px[R], py[R], pz[R];
     uint32_t lab[R];
     unsigned long long m[R];
@@ -552,6 +565,22 @@ template <int GEN, int LEAFW, bool UNI, bool SPEC, bool STATS = false, int QN = 
 __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) void trace_kernel(const TraceParams p) {
     extern __shared__ int s_stack[];   // [stack depth][kTBlock]: one column per lane, conflict free
     const uint32_t tid = threadIdx.x;
+    if (GEN == 1 && p.pre.blocks != 0u && p.pre.sharded != 0u) {
+        if (blockIdx.x < p.pre.blocks) {
+            // per-pose counts of the assembled cloud (one thread per pose of ALL ranks), then this workgroup's share
+            rebuild_counts(p.pre.rq, blockIdx.x * kTBlock + tid, p.pre.blocks * kTBlock);
+            if (blockIdx.x < p.pre.own_blocks) {
+                const uint64_t tile0 = (uint64_t)blockIdx.x * kPreTiles;
+                if (tile0 < p.pre.ntiles)
+                    scatter_tiles_xyzl<kPreTiles>(p.pre.io, p.pre.ntiles, tile0, tid, p.pre.tile_off, nullptr, p.pre.tile_base,
+                                                  p.pre.super_base);
+            } else {
+                const uint32_t tile0 = (blockIdx.x - p.pre.own_blocks) * (uint32_t)LRC_REBUILD_R;
+                if (tile0 < p.pre.rq.ntiles) rebuild_tiles<LRC_REBUILD_R>(p.pre.rq, tile0, p.pre.rq.ntiles, tid);
+            }
+            return;
+        }
+    } else
     if (GEN == 1 && p.pre.blocks != 0u) {          // wave-uniform; only the pose-batched scan is ever pipelined
         if (blockIdx.x < p.pre.blocks) {
             if (p.pre.io.counts) segment_count(p.pre.io, p.pre.tps, p.pre.ntiles, p.pre.nseg, (uint64_t)blockIdx.x * kTBlock + tid,
@@ -2326,6 +2355,7 @@ static int ensure_tile_scratch(lrc_ctx* ctx, lrc_ctx::TileScratch& sc, uint64_t 
 // record sets: set k is read by launch k+2 and written again by launch k+4, both on its own stream.
 struct lrc_pipe {
     lrc_scene* scene = nullptr;
+    int device = 0;
     uint64_t max_poses = 0, rays_per_pose = 0, cap = 0;      // cap = max_poses * rays_per_pose records per set
     static constexpr int kSets = 4;
     void* slab[kSets] = {};                                  // one allocation per record set
@@ -2338,11 +2368,16 @@ struct lrc_pipe {
     hipEvent_t ev_in[kSets] = {}, ev_t0[kSets] = {}, ev_trace[kSets] = {}, ev_flush[2] = {};
     bool fused = true;                                       // false: N % 64 != 0 or > 512 super tiles: plain chain per stream
     uint64_t ticket = 0;                                     // submits so far; submit k uses set k % 4, trace stream k % 2
+    // sharded submits (lrc_pipe_submit_sharded): scratch of the scan over ALL ranks' keep counts, per trace stream, and the
+    // direction table transposed for the rebuild (once per table)
+    lrc_ctx::TileScratch gscratch[2];
+    double* d_dirs_soa = nullptr;
+    const double* soa_of = nullptr;
 };
 
 int lrc_pipe_destroy(lrc_pipe* pp) {
     if (!pp) return LRC_OK;
-    if (pp->scene && pp->scene->ctx) (void)hipSetDevice(pp->scene->ctx->device);
+    (void)hipSetDevice(pp->device);
     for (hipStream_t st : {pp->s_trace[0], pp->s_trace[1]})
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (int k = 0; k < lrc_pipe::kSets; ++k) {
@@ -2351,12 +2386,15 @@ int lrc_pipe_destroy(lrc_pipe* pp) {
     }
     for (int k = 0; k < 2; ++k) {
         if (pp->ev_flush[k]) (void)hipEventDestroy(pp->ev_flush[k]);
-        lrc_ctx::TileScratch& sc = pp->scratch[k];
-        if (sc.d_tile_off) (void)hipFree(sc.d_tile_off);
-        if (sc.d_tile_cnt) (void)hipFree(sc.d_tile_cnt);
-        if (sc.d_super_total) (void)hipFree(sc.d_super_total);
-        if (sc.d_super_base) (void)hipFree(sc.d_super_base);
+        for (lrc_ctx::TileScratch* scp : {&pp->scratch[k], &pp->gscratch[k]}) {
+            lrc_ctx::TileScratch& sc = *scp;
+            if (sc.d_tile_off) (void)hipFree(sc.d_tile_off);
+            if (sc.d_tile_cnt) (void)hipFree(sc.d_tile_cnt);
+            if (sc.d_super_total) (void)hipFree(sc.d_super_total);
+            if (sc.d_super_base) (void)hipFree(sc.d_super_base);
+        }
     }
+    if (pp->d_dirs_soa) (void)hipFree(pp->d_dirs_soa);
     delete pp;
     return LRC_OK;
 }
@@ -2372,6 +2410,7 @@ int lrc_pipe_create(lrc_scene* s, uint64_t max_poses, uint64_t rays_per_pose, lr
     lrc_pipe* pp = new (std::nothrow) lrc_pipe();
     if (!pp) return fail(LRC_ERR_OOM, "lrc_pipe_create: out of host memory");
     pp->scene = s;
+    pp->device = s->ctx->device;
     pp->max_poses = max_poses;
     pp->rays_per_pose = rays_per_pose;
     const uint64_t n = pp->cap = max_poses * rays_per_pose;
@@ -2484,6 +2523,174 @@ int lrc_pipe_submit(lrc_pipe* pp, const double* d_poses16, uint64_t P, const dou
     }
     pp->ticket = k + 1;
     if (out_ticket) *out_ticket = k + 1;
+    return LRC_OK;
+}
+
+// ---- the pipeline on N ranks: the trace writes triangle ids + keep counts into the caller's send slab, the assembly of an
+// EARLIER scan of all ranks (its gathered slabs) rides in the leading workgroups of this trace launch ----------------------
+namespace {
+int check_gathered(const lrc_pipe* pp, const lrc_gathered* g, const char* who) {
+    auto bad = [&](const char* m) { return fail(LRC_ERR_INVALID_ARG, std::string(who) + ": " + m); };
+    if (!g->d_all_poses16 || !g->d_all_prims || !g->d_all_tile_counts || !g->d_out_xyzl) return bad("NULL member of lrc_gathered");
+    if (g->poses_per_slab == 0 || g->poses_per_slab > pp->max_poses || g->num_poses_all == 0 || g->num_poses_all % g->poses_per_slab)
+        return bad("num_poses_all must be a multiple of poses_per_slab (<= the pipeline's max_poses)");
+    if (g->own_slab >= g->num_poses_all / g->poses_per_slab) return bad("own_slab outside the gathered slabs");
+    if (g->slab_stride_bytes % 4 || g->slab_stride_bytes < g->poses_per_slab * pp->rays_per_pose * 4) return bad("slab stride smaller than a slab");
+    if (g->own_ticket == 0 || g->own_ticket > pp->ticket || pp->ticket - g->own_ticket >= (uint64_t)lrc_pipe::kSets)
+        return bad("the own records of that scan are gone (four sets rotate): assemble within three submits");
+    const uint64_t ntiles = g->num_poses_all * (pp->rays_per_pose / 64);
+    if (ntiles > 0x7FFFFFFFull) return bad("too many entries");
+    return LRC_OK;
+}
+
+// scan over all ranks' keep counts (two one-wave kernels on `st`), the rebuild's argument block, the own rows' compaction input
+// the scan over all ranks' keep counts (two one-wave kernels on `st`) into the scratch set of g->scan_slot; also what a first
+// use needs: the plane table, the transposed direction table
+int scan_gathered(lrc_pipe* pp, const lrc_gathered* g, const double* d_dirs3, hipStream_t st, int scan_waves) {
+    lrc_scene* s = pp->scene;
+    lrc_ctx::TileScratch& sc = pp->gscratch[g->scan_slot & 1u];
+    const uint64_t N = pp->rays_per_pose, tps = N / 64, ntiles = g->num_poses_all * tps;
+    int rc = ensure_tile_scratch(s->ctx, sc, ntiles);
+    if (rc) return rc;
+    if ((rc = ensure_prim_plane(s, st))) return rc;
+    if (pp->soa_of != d_dirs3) {
+        if (!pp->d_dirs_soa) LRC_HIP(hipMalloc((void**)&pp->d_dirs_soa, N * 24));
+        hipLaunchKernelGGL(dirs_transpose_kernel, dim3((uint32_t)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, d_dirs3, (uint32_t)N,
+                           pp->d_dirs_soa);
+        LRC_HIP(hipStreamSynchronize(st));          // once per table: the trace streams read it
+        pp->soa_of = d_dirs3;
+    }
+    const uint64_t stride = g->slab_stride_bytes / 4, nsuper = (ntiles + 1023) / 1024;
+    const uint64_t grid = scan_waves > 0 && nsuper > (uint64_t)scan_waves ? (uint64_t)scan_waves : nsuper;
+    hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)grid), dim3(64), 0, st, g->d_all_tile_counts, g->poses_per_slab * tps, stride,
+                       sc.d_tile_off, ntiles, sc.d_super_total);
+    hipLaunchKernelGGL(compact_base_kernel, dim3(1), dim3(64), 0, st, (const uint32_t*)sc.d_super_total, sc.d_super_base, nsuper);
+    LRC_HIP(hipGetLastError());
+    return LRC_OK;
+}
+
+// the rebuild's argument block and the own rows' compaction input, for a gathered scan whose counts have been scanned
+int prepare_gathered(lrc_pipe* pp, const lrc_gathered* g, RebuildParams* q, lrc_compact_io* own_io, uint64_t* own_tiles,
+                     uint64_t* tile_base) {
+    lrc_scene* s = pp->scene;
+    lrc_ctx::TileScratch& sc = pp->gscratch[g->scan_slot & 1u];
+    const uint64_t N = pp->rays_per_pose, tps = N / 64, ntiles = g->num_poses_all * tps;
+    if (sc.tile_cap < ntiles + 1 || !pp->d_dirs_soa || !s->d_prim_plane)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_pipe: the gathered scan has not been through lrc_pipe_scan_gathered");
+    const uint64_t stride = g->slab_stride_bytes / 4;
+    q->poses16 = g->d_all_poses16; q->dirs_soa = pp->d_dirs_soa; q->prims = g->d_all_prims;
+    q->pps = (uint32_t)g->poses_per_slab; q->stride = stride; q->seg_len = (uint32_t)N; q->tps = (uint32_t)tps;
+    q->ntiles = (uint32_t)ntiles; q->nseg = (uint32_t)g->num_poses_all; q->plane = s->d_prim_plane;
+    q->num_prims = (uint32_t)s->info.num_triangles; q->tile_off = sc.d_tile_off; q->super_base = sc.d_super_base;
+    q->out_xyzl = (float4*)g->d_out_xyzl; q->counts = g->d_counts; q->skip_slab = (uint32_t)g->own_slab;
+    const lrc_hits& h = pp->rec[(g->own_ticket - 1) % lrc_pipe::kSets];
+    *own_io = lrc_compact_io{};
+    own_io->t = h.t; own_io->point3 = h.point3; own_io->sem = h.sem; own_io->ins = h.ins;
+    own_io->out_xyzl = g->d_out_xyzl;
+    *own_tiles = pp->poses[(g->own_ticket - 1) % lrc_pipe::kSets] * tps;
+    *tile_base = g->own_slab * g->poses_per_slab * tps;
+    return LRC_OK;
+}
+}  // namespace
+
+int lrc_pipe_submit_sharded(lrc_pipe* pp, const double* d_poses16, uint64_t P, const double* d_dirs3, double max_range,
+                            uint32_t* d_send_prim, uint32_t* d_send_tile_count, const lrc_gathered* assemble, void* stream,
+                            uint64_t* out_ticket) {
+    if (!pp) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_submit_sharded: pipe is NULL");
+    if (!pp->fused) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_submit_sharded: needs rays_per_pose % 64 == 0");
+    if (P == 0 || P > pp->max_poses) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_submit_sharded: pose count outside (0, max_poses]");
+    if (!d_poses16 || !d_dirs3 || !d_send_prim || !d_send_tile_count)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_submit_sharded: NULL poses, table or send slab");
+    lrc_scene* s = pp->scene;
+    if (s->opts.range_noise)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_submit_sharded: a scan with range noise cannot be rebuilt from triangle ids");
+    LRC_HIP(hipSetDevice(s->ctx->device));
+    int rc;
+    if (assemble && (rc = check_gathered(pp, assemble, "lrc_pipe_submit_sharded"))) return rc;
+    const uint64_t k = pp->ticket;
+    const int set = (int)(k % lrc_pipe::kSets), lane = (int)(k % 2);
+    hipStream_t T = pp->s_trace[lane];
+    // inputs, the send slab and -- for the assembly -- the gathered slabs are the caller's as of this point of its stream
+    LRC_HIP(hipEventRecord(pp->ev_in[set], (hipStream_t)stream));
+    LRC_HIP(hipStreamWaitEvent(T, pp->ev_in[set], 0));
+    const uint64_t N = pp->rays_per_pose;
+    TraceParams p{};
+    p.poses16 = d_poses16; p.dirs3 = d_dirs3; p.rays_per_pose = N; p.total = P * N; p.has_center = 1; p.max_range = max_range;
+    p.out = pp->rec[set];
+    p.out.prim = d_send_prim;                  // the 36-byte record stays complete: its id column IS the send slab
+    p.out.tile_count = d_send_tile_count;
+    lrc_compact_io own_io{};
+    if (assemble) {
+        uint64_t own_tiles = 0, tile_base = 0;
+        if ((rc = prepare_gathered(pp, assemble, &p.pre.rq, &own_io, &own_tiles, &tile_base))) return rc;
+        p.pre.sharded = 1;
+        p.pre.io = own_io;
+        p.pre.ntiles = own_tiles;
+        p.pre.seg_len = N; p.pre.tps = N / 64;
+        p.pre.tile_off = pp->gscratch[assemble->scan_slot & 1u].d_tile_off;
+        p.pre.super_base = pp->gscratch[assemble->scan_slot & 1u].d_super_base;
+        p.pre.tile_base = tile_base;
+        p.pre.own_blocks = (uint32_t)((own_tiles + kPreTiles - 1) / kPreTiles);
+        const uint64_t rb = ((uint64_t)p.pre.rq.ntiles + LRC_REBUILD_R - 1) / LRC_REBUILD_R;
+        const uint64_t need = ((uint64_t)p.pre.rq.nseg + kTBlock - 1) / kTBlock;        // threads for the per-pose counts
+        uint64_t blocks = p.pre.own_blocks + rb;
+        if (blocks < need) blocks = need;
+        p.pre.blocks = (uint32_t)blocks;
+    }
+    LRC_HIP(hipEventRecord(pp->ev_t0[set], T));
+    rc = launch_trace(s, p, 1, T);
+    if (rc) return rc;
+    LRC_HIP(hipEventRecord(pp->ev_trace[set], T));
+    pp->out[set] = lrc_compact_io{};
+    pp->poses[set] = P;
+    pp->pending[set] = false;                  // nothing local to scatter: the rows appear when the gathered scan is assembled
+    pp->ticket = k + 1;
+    if (out_ticket) *out_ticket = k + 1;
+    return LRC_OK;
+}
+
+int lrc_pipe_trace_done(lrc_pipe* pp, uint64_t ticket, void* stream) {
+    if (!pp) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_trace_done: pipe is NULL");
+    if (ticket == 0 || ticket > pp->ticket || pp->ticket - ticket >= (uint64_t)lrc_pipe::kSets)
+        return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_trace_done: the events of that submit have been reused");
+    LRC_HIP(hipSetDevice(pp->scene->ctx->device));
+    LRC_HIP(hipStreamWaitEvent((hipStream_t)stream, pp->ev_trace[(ticket - 1) % lrc_pipe::kSets], 0));
+    return LRC_OK;
+}
+
+// the scan over the gathered keep counts, on the caller's COMMUNICATION stream right behind the collective: two one-wave kernels
+// that trickle in beside the running trace launch and have a whole step before the launch that carries the assembly needs them
+// (between two trace launches of one stream they would hold the second back: DESIGN.md section 5.2)
+int lrc_pipe_scan_gathered(lrc_pipe* pp, const double* d_dirs3, const lrc_gathered* g, void* stream) {
+    if (!pp || !g || !d_dirs3) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_scan_gathered: NULL argument");
+    int rc = check_gathered(pp, g, "lrc_pipe_scan_gathered");
+    if (rc) return rc;
+    LRC_HIP(hipSetDevice(pp->device));
+    return scan_gathered(pp, g, d_dirs3, (hipStream_t)stream, LRC_PIPE_SCAN_WAVES * 4);
+}
+
+// the assembly of a gathered (and scanned) scan with the plain kernels, on `stream` (the end of a run: no later launch to ride on)
+int lrc_pipe_assemble(lrc_pipe* pp, const double* d_dirs3, const lrc_gathered* g, void* stream) {
+    if (!pp || !g || !d_dirs3) return fail(LRC_ERR_INVALID_ARG, "lrc_pipe_assemble: NULL argument");
+    int rc = check_gathered(pp, g, "lrc_pipe_assemble");
+    if (rc) return rc;
+    LRC_HIP(hipSetDevice(pp->scene->ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    // the own records were written by a trace on an internal stream
+    LRC_HIP(hipStreamWaitEvent(st, pp->ev_trace[(g->own_ticket - 1) % lrc_pipe::kSets], 0));
+    RebuildParams q{};
+    lrc_compact_io io{};
+    uint64_t own_tiles = 0, tile_base = 0;
+    if ((rc = prepare_gathered(pp, g, &q, &io, &own_tiles, &tile_base))) return rc;
+    constexpr int kR = LRC_REBUILD_R;
+    const uint64_t wblocks = (((uint64_t)q.ntiles + kR - 1) / kR + kBlock / 64 - 1) / (kBlock / 64);
+    hipLaunchKernelGGL(prim_scatter_kernel<kR>, dim3((uint32_t)(wblocks ? wblocks : 1)), dim3(kBlock), 0, st, q);
+    const uint64_t N = pp->rays_per_pose, tps = N / 64;
+    const uint64_t nblocks = (own_tiles + kBlock / 64 - 1) / (kBlock / 64);
+    if (nblocks)
+        hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)nblocks), dim3(kBlock), 0, st, io, N, tps, own_tiles, own_tiles / tps,
+                           (const uint32_t*)q.tile_off, (const uint64_t*)q.super_base, tile_base, (const uint32_t*)nullptr);
+    LRC_HIP(hipGetLastError());
     return LRC_OK;
 }
 

@@ -28,6 +28,7 @@ SYMBOLS = (
     "lrc_cast", "lrc_cast_dev", "lrc_cast_segments", "lrc_cast_segments_dev",
     "lrc_scan_poses", "lrc_scan_poses_dev", "lrc_scan_poses_compact", "lrc_host_alloc", "lrc_host_free",
     "lrc_pipe_create", "lrc_pipe_destroy", "lrc_pipe_submit", "lrc_pipe_wait", "lrc_pipe_records", "lrc_pipe_trace_ms",
+    "lrc_pipe_submit_sharded", "lrc_pipe_trace_done", "lrc_pipe_scan_gathered", "lrc_pipe_assemble",
     "lrc_scan_angles_dev", "lrc_scan_angles_compact", "lrc_debug_scan_stats",
     "lrc_scan_grid_dev", "lrc_scan_grid_compact", "lrc_scan_rays_compact",
     "lrc_table_create", "lrc_table_destroy", "lrc_scan_table_compact",
@@ -68,6 +69,13 @@ class LrcCompactIO(C.Structure):
                 ("out_point3", C.c_void_p), ("out_sem", C.c_void_p), ("out_ins", C.c_void_p),
                 ("out_incident_deg", C.c_void_p), ("out_index", C.c_void_p), ("out_xyzl", C.c_void_p),
                 ("out_range_origin", C.c_void_p)]
+
+
+class LrcGathered(C.Structure):
+    _fields_ = [("d_all_poses16", C.c_void_p), ("num_poses_all", C.c_uint64), ("d_all_prims", C.c_void_p),
+                ("d_all_tile_counts", C.c_void_p), ("poses_per_slab", C.c_uint64), ("slab_stride_bytes", C.c_uint64),
+                ("own_slab", C.c_uint64), ("own_ticket", C.c_uint64), ("scan_slot", C.c_uint64), ("d_out_xyzl", C.c_void_p),
+                ("d_counts", C.c_void_p)]
 
 
 class LrcFrames(C.Structure):
@@ -137,6 +145,10 @@ def load():
         "lrc_pipe_wait": [vp, vp],
         "lrc_pipe_records": [vp, u64, C.POINTER(LrcHits)],
         "lrc_pipe_trace_ms": [vp, u64, C.POINTER(C.c_float)],
+        "lrc_pipe_submit_sharded": [vp, vp, u64, vp, dbl, vp, vp, C.POINTER(LrcGathered), vp, C.POINTER(u64)],
+        "lrc_pipe_trace_done": [vp, u64, vp],
+        "lrc_pipe_scan_gathered": [vp, vp, C.POINTER(LrcGathered), vp],
+        "lrc_pipe_assemble": [vp, vp, C.POINTER(LrcGathered), vp],
         "lrc_host_alloc": [vp, u64, C.POINTER(vp)],
         "lrc_host_free": [vp, vp],
         "lrc_scan_angles_dev": [vp, vp, u64, vp, vp, u64, dbl, C.POINTER(LrcHits), vp],

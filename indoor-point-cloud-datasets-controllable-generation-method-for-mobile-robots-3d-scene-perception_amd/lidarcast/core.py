@@ -748,6 +748,42 @@ class ScanPipe:
     def wait(self, stream=0):
         check(self._lib.lrc_pipe_wait(self._h, C.c_void_p(int(stream))), "lrc_pipe_wait")
 
+    # ---- N ranks: ids + keep counts into the caller's send slab, an earlier gathered scan assembled in the launch's front ----
+    @staticmethod
+    def gathered(all_poses_t, all_prims_t, all_tile_counts_t, poses_per_slab, slab_stride_bytes, own_slab, own_ticket,
+                 out_rows_t, counts_t=None, scan_slot=0):
+        """An lrc_gathered for submit_sharded / assemble: the slabs of ALL ranks after the collective (torch tensors)."""
+        g = _capi.LrcGathered()
+        g.d_all_poses16, g.num_poses_all = all_poses_t.data_ptr(), all_poses_t.shape[0]
+        g.d_all_prims, g.d_all_tile_counts = all_prims_t.data_ptr(), all_tile_counts_t.data_ptr()
+        g.poses_per_slab, g.slab_stride_bytes = int(poses_per_slab), int(slab_stride_bytes)
+        g.own_slab, g.own_ticket, g.scan_slot = int(own_slab), int(own_ticket), int(scan_slot)
+        g.d_out_xyzl = out_rows_t.data_ptr()
+        g.d_counts = counts_t.data_ptr() if counts_t is not None else None
+        return g
+
+    def submit_sharded(self, poses_t, dirs_t, max_range, send_prim_t, send_tile_count_t, assemble=None, stream=0):
+        ticket = C.c_uint64(0)
+        check(self._lib.lrc_pipe_submit_sharded(
+            self._h, C.c_void_p(poses_t.data_ptr()), poses_t.shape[0], C.c_void_p(dirs_t.data_ptr()), float(max_range),
+            C.c_void_p(send_prim_t.data_ptr()), C.c_void_p(send_tile_count_t.data_ptr()),
+            C.byref(assemble) if assemble is not None else None, C.c_void_p(int(stream)), C.byref(ticket)),
+            "lrc_pipe_submit_sharded")
+        return ticket.value
+
+    def trace_done(self, ticket, stream=0):
+        """``stream`` waits for the trace of that submit: its send slab is complete, the collective may start."""
+        check(self._lib.lrc_pipe_trace_done(self._h, int(ticket), C.c_void_p(int(stream))), "lrc_pipe_trace_done")
+
+    def scan_gathered(self, dirs_t, gathered, stream=0):
+        """The scan over the gathered keep counts: enqueue on the communication stream right behind the collective."""
+        check(self._lib.lrc_pipe_scan_gathered(self._h, C.c_void_p(dirs_t.data_ptr()), C.byref(gathered), C.c_void_p(int(stream))),
+              "lrc_pipe_scan_gathered")
+
+    def assemble(self, dirs_t, gathered, stream=0):
+        check(self._lib.lrc_pipe_assemble(self._h, C.c_void_p(dirs_t.data_ptr()), C.byref(gathered), C.c_void_p(int(stream))),
+              "lrc_pipe_assemble")
+
     def records(self, ticket):
         """LrcHits (device pointers) of the fixed-stride records of that submit; valid until two further submits."""
         h = _capi.LrcHits()

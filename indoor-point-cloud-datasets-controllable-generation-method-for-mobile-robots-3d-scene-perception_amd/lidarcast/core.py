@@ -716,8 +716,8 @@ class Scene:
 
 class ScanPipe:
     """Consecutive pose batches of one scene, scanned and compacted with the launches overlapped inside the library
-    (lrc_pipe_*: the trace of batch k+1 fills the wave slots the trace of batch k leaves empty in its tail; the compaction
-    runs beside it at high stream priority).  Everything stays in HBM; `submit` only enqueues, `wait` orders a stream
+    (lrc_pipe_*: the trace of batch k+1 fills the wave slots the trace of batch k leaves empty in its tail; the rows of
+    batch k are scattered by the leading workgroups of the trace launch of batch k+2).  Everything stays in HBM; `submit` only enqueues, `wait` orders a stream
     behind all submits so far.  The poses of a trajectory are independent (reference: s3dis_simulator.py:254-288)."""
 
     def __init__(self, scene, max_poses, rays_per_pose):

@@ -839,7 +839,8 @@ def test_bench_contract():
 def test_two_rank_launch_of_the_bench_path():
     """The N > 1 path launched the way the driver launches it (torch.distributed.run, one process per rank), two
     ranks sharing this one GPU with the collective staged through gloo (RCCL refuses two ranks on one device): pose
-    sharding by rank, the gather of triangle ids, and on EVERY rank a rebuilt scene cloud equal to the local
+    sharding by rank, the gather of triangle ids -- as separate kernels (`prim`) and through the scan pipeline
+    (`prim_pipe`: lrc_pipe_submit_sharded) --, and on EVERY rank a rebuilt scene cloud equal to the local
     compaction of all ranks' poses, bit for bit.  (With world size 1 the same code runs through RCCL: the
     --dist-selftest runs in DESIGN.md section 6.)"""
     import json
@@ -851,18 +852,26 @@ def test_two_rank_launch_of_the_bench_path():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, LRC_DIST_BACKEND="gloo")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
-                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-selftest"],
-                       capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert r.stderr.count("dist selftest ok") == 2 and "world 2" in r.stderr
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(line) == 1                                      # rank 0 alone prints
-    res = json.loads(line[0])
-    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and "cpu_baseline" not in res
-    assert res["config"]["rays_per_step_per_gpu"] == 64 * 65536 and 0.99 < res["config"]["hit_fraction"] <= 1.0
+    seen = set()
+    for forced in (None, "prim_pipe", "prim"):                 # the calibrated choice, then each id payload by name
+        if forced in seen:
+            continue
+        env = dict(os.environ, LRC_DIST_BACKEND="gloo")
+        if forced:
+            env["LRC_DIST_PAYLOAD"] = forced
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+                            "--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-selftest"],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stderr.count("dist selftest ok") == 2 and "world 2" in r.stderr
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(line) == 1                                  # rank 0 alone prints
+        res = json.loads(line[0])
+        assert res["n_gpus"] == 2 and res["scaling"] == "weak" and "cpu_baseline" not in res
+        assert res["config"]["rays_per_step_per_gpu"] == 64 * 65536 and 0.99 < res["config"]["hit_fraction"] <= 1.0
+        assert forced is None or res["config"]["gather_payload"] == forced
+        seen.add(res["config"]["gather_payload"])
 
 
 def test_cast_segments_ragged_poses(engine, a1):
@@ -1364,3 +1373,106 @@ def _dev_bytes(ptr, nbytes):
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     assert hip.hipMemcpy(C.c_void_p(buf.data_ptr()), C.c_void_p(int(ptr)), nbytes, 3) == 0      # device to device
     return buf.cpu().numpy().tobytes()
+
+
+def test_sharded_scan_pipeline_assembles_the_scene_cloud(ctx):
+    """The N-rank form of the pipeline (lrc_pipe_submit_sharded / trace_done / scan_gathered / assemble), three ranks
+    emulated on one GPU: this rank (the MIDDLE slab, so that rows land before and after its own) traces its pose block with
+    ids and keep counts written into its send slab; the "collective" -- here a copy of that slab plus scans of the other
+    ranks' poses into their slabs, on a communication stream behind lrc_pipe_trace_done -- is followed by the scan over the
+    gathered counts; the assembly of step s rides in the leading workgroups of the trace launch of step s+2, the last two
+    steps go through lrc_pipe_assemble.  Every step has its own poses; every step's cloud and per-pose counts must equal
+    the local scan + compaction of all ranks' poses of that step, bit for bit (np.vstack order, reference:
+    containers/s3dis_sim_scene.py:326)."""
+    import torch
+    import lidarcast
+    from lidarcast import synth
+    from lidarcast._capi import LrcCompactIO
+    from lidarcast.distributed import PrimGather
+    from lidar import IndoorLidar
+
+    class OneRank:                     # PrimGather only asks the process group for its size when sizing the receive view
+        @staticmethod
+        def get_world_size(group=None):
+            return 1
+
+    mesh = synth.make_room(size=(4, 3, 2.5), num_boxes=4, seed=5, cell=0.04)
+    scene = lidarcast.Scene(ctx, mesh.vertices, mesh.triangles, mesh.triangle_sem, mesh.triangle_ins)
+    dev = torch.device("cuda", 0)
+    main = torch.cuda.current_stream()
+    comm = torch.cuda.Stream(device=dev)
+    rng = np.random.default_rng(11)
+    W, own = 3, 1
+    for lines, width, max_range, P, steps in ((8, 512, 2.5, 5, 7), (4, 256, 20.0, 19, 5), (16, 1024, 3.0, 3, 4)):
+        k = sensor_small(lines=lines, width=width, max_range=max_range)
+        dirs = IndoorLidar(k, np.eye(4)).sensor_directions()
+        N = len(dirs)
+        d_dirs = torch.from_numpy(dirs).to(dev)
+        pipe = lidarcast.ScanPipe(scene, P, N)
+        gathers = [PrimGather(P, N, OneRank, dev, world=W) for _ in range(2)]
+        tl = lidarcast.DeviceHits(0, dev, want=())
+        all_poses, clouds, cnts, tickets, scanned = [], [], [], [0, 0], [None, None]
+
+        def job_of(kk, s):
+            g = gathers[kk]
+            return lidarcast.ScanPipe.gathered(all_poses[s], g.all_prims, g.all_tile_counts, P, g.stride_bytes, own,
+                                               tickets[kk], clouds[s], cnts[s], scan_slot=kk)
+
+        for s in range(steps):
+            poses = np.stack([pose(0.6 + 2.8 * rng.random(), 0.6 + 1.8 * rng.random(), 0.5 + 1.5 * rng.random(),
+                                   yaw=rng.uniform(-3, 3)) for _ in range(W * P)])
+            all_poses.append(torch.from_numpy(poses.reshape(W * P, 16)).to(dev))
+            clouds.append(torch.full((W * P * N, 4), -7.0, dtype=torch.float32, device=dev))
+            cnts.append(torch.full((W * P,), -1, dtype=torch.int64, device=dev))
+            kk = s % 2
+            g = gathers[kk]
+            asm = None
+            if scanned[kk] is not None:
+                main.wait_event(scanned[kk])
+                asm = job_of(kk, s - 2)
+            tickets[kk] = pipe.submit_sharded(all_poses[s][own * P:(own + 1) * P], d_dirs, k.max_range, g.prim, g.tile_count,
+                                              assemble=asm, stream=main.cuda_stream)
+            pipe.trace_done(tickets[kk], comm.cuda_stream)
+            with torch.cuda.stream(comm):
+                g.all_slabs[own * g.words:(own + 1) * g.words].copy_(g.slab)
+                for v in range(W):
+                    if v != own:
+                        tl.struct.prim = g.all_slabs[v * g.words:].data_ptr()
+                        tl.struct.tile_count = g.all_slabs[v * g.words + g.n:].data_ptr()
+                        scene.scan_poses_dev(all_poses[s][v * P:(v + 1) * P], d_dirs, tl, k.max_range, comm.cuda_stream)
+                pipe.scan_gathered(d_dirs, job_of(kk, s), comm.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(comm)
+            scanned[kk] = ev
+        for s in (steps - 2, steps - 1):
+            kk = s % 2
+            main.wait_event(scanned[kk])
+            pipe.assemble(d_dirs, job_of(kk, s), main.cuda_stream)
+        pipe.wait(main.cuda_stream)
+        torch.cuda.synchronize()
+        hits = lidarcast.DeviceHits(W * P * N, dev, want=("t", "point3", "sem", "ins", "tile_count"))
+        for s in range(steps):
+            rows2 = torch.full_like(clouds[s], -7.0)
+            counts2 = torch.full_like(cnts[s], -1)
+            io2 = LrcCompactIO()
+            io2.t, io2.point3, io2.sem, io2.ins = (hits[a].data_ptr() for a in ("t", "point3", "sem", "ins"))
+            io2.tile_count, io2.counts, io2.out_xyzl = hits["tile_count"].data_ptr(), counts2.data_ptr(), rows2.data_ptr()
+            scene.scan_poses_dev(all_poses[s], d_dirs, hits, k.max_range, main.cuda_stream)
+            ctx.compact_dev(W * P, N, io2, main.cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(cnts[s], counts2), f"per-pose counts differ, step {s}"
+            kept = int(counts2.sum().item())
+            assert 0 < kept and (kept < W * P * N or max_range > 10)
+            assert torch.equal(clouds[s][:kept].view(torch.int32), rows2[:kept].view(torch.int32)), f"rows differ, step {s}"
+            assert bool((clouds[s][kept:] == -7.0).all()), "rows beyond the kept ones were touched"
+        # argument checks: an assembly whose own records have rotated away, a slab outside the gathered ones
+        stale = job_of(0, 0)
+        stale.own_ticket = 1
+        if steps > 4:
+            with pytest.raises(ValueError):
+                pipe.assemble(d_dirs, stale, main.cuda_stream)
+        outside = job_of(0, steps - 2 if (steps - 2) % 2 == 0 else steps - 1)
+        outside.own_slab = W
+        with pytest.raises(ValueError):
+            pipe.assemble(d_dirs, outside, main.cuda_stream)
+        pipe.close()

@@ -13,11 +13,14 @@ SCENE_ARGS=${PMC_SCENE:+--scene $PMC_SCENE}
 # workgroups in front: not what the roofline prices); short timed phase, the counters are per launch
 ARGS="${PMC_ARGS:---serial --steps 3 --warmup 1 --min-seconds 0.05 --no-cpu-baseline --no-caller-path} $SCENE_ARGS"
 export PMC_ARGS="$ARGS"
+# PMC_SCRIPT="tools/rebuild_time.py 8": profile another script of the repo instead of bench.py (its own arguments included)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
+TARGET="$R/bench.py $ARGS"
+[ -n "${PMC_SCRIPT:-}" ] && TARGET="$R/$PMC_SCRIPT"
 i=0
 for grp in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" \
@@ -27,7 +30,7 @@ for grp in \
   "FETCH_SIZE" \
   "WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" ; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 $R/bench.py $ARGS > $OUT/p$i.log 2>&1 || { echo "pass $i FAILED: $grp"; FAILED=1; }
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 $TARGET > $OUT/p$i.log 2>&1 || { echo "pass $i FAILED: $grp"; FAILED=1; }
 done
 python3 $R/tools/pmc_summary.py $OUT $PAT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

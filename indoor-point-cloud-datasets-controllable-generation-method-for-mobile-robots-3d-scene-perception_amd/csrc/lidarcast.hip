@@ -308,10 +308,10 @@ __device__ __forceinline__ void rebuild_tiles(const RebuildParams& q, uint32_t t
             da[k] = q.dirs_soa[idx[k]];
             db[k] = q.dirs_soa[(size_t)q.seg_len + idx[k]];
             dc[k] = q.dirs_soa[2 * (size_t)q.seg_len + idx[k]];
-            if (prim[k] < q.num_prims) {   // an id that is not a triangle of this scene: zero plane, never a wild read
-                pa[k] = q.plane[(size_t)prim[k] * 2];
-                pb[k] = q.plane[(size_t)prim[k] * 2 + 1];
-            }
+        }
+        if (keep[k] && prim[k] < q.num_prims) {   // an id that is not a triangle of this scene: zero plane, never a wild read
+            pa[k] = q.plane[(size_t)prim[k] * 2];
+            pb[k] = q.plane[(size_t)prim[k] * 2 + 1];
         }
     }
 #pragma unroll
@@ -801,7 +801,13 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
 #pragma unroll
                 for (int j = 0; j < LEAFW; ++j) {
                     const float4* tr = p.tris + (size_t)(first + k0 + j) * 3;
+#ifdef LRC_TRI36
+                    // A/B only (profiles/r04_trace_levers.txt): 36 of the record's 48 bytes come back, Ng = cross(e2, e1) is
+                    // formed again (the builder's own expression: same bits) -- one dwordx4 return per test for six VALU
+                    ra[j] = tr[0]; rb[j] = tr[1]; rc[j].x = ((const float*)tr)[8];
+#else
                     ra[j] = tr[0]; rb[j] = tr[1]; rc[j] = tr[2];
+#endif
                 }
 #pragma unroll
                 for (int j = 0; j < LEAFW; ++j) {
@@ -809,7 +815,11 @@ __global__ __launch_bounds__(kTBlock, (QN != 0 && !STATS && GEN == 1) ? 8 : 1) v
                         if (STATS) st_tris += 1u;
                         const uint32_t slot = first + k0 + j;
                         const float4 a = ra[j], b = rb[j], c = rc[j];
+#ifdef LRC_TRI36
+                        const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng = cross3(v2, v1);
+#else
                         const V3 v0{a.x, a.y, a.z}, v1{a.w, b.x, b.y}, v2{b.z, b.w, c.x}, ng{c.y, c.z, c.w};
+#endif
                         float t;
                         bool hit;
                         // edge records (v0, e1, e2, Ng): v1 / v2 above ARE e1 / e2.  Candidates are ranked by the

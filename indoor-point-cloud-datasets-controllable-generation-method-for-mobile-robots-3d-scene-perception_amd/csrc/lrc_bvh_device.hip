@@ -193,6 +193,27 @@ DI void store_prim(PrimRec* p, const LoadedPrim& r) {
 }
 
 // ---- setup: primitive records, scene bounds, root centroid bounds, input validation --------------------------------
+// The state a build starts from, in one launch (it used to be three memsets, seven four-byte copies and a synchronisation):
+// all level counters zero, level 0 = the root alone in the list of its size class, empty scene bounds, the root node.
+struct SetupArgs { TNode* nodes; LevelCounters* counters; int* bounds; uint32_t* qfail; uint32_t* sub_count; uint32_t* list0[4]; uint32_t T; };
+__global__ __launch_bounds__(256) void k_setup(const SetupArgs a) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t* cw = (uint32_t*)a.counters;
+    for (uint32_t i = tid; i < (uint32_t)(sizeof(LevelCounters) / 4 * (kMaxLevels + 1)); i += 256) cw[i] = 0u;
+    if (tid < 8) { a.bounds[tid] = tid < 3 ? kEncPosMax : (tid < 6 ? kEncNegMax : 0); a.sub_count[tid] = 0u; }
+    if (tid < 4) { a.qfail[tid] = 0u; a.list0[tid][0] = 0u; }
+    __syncthreads();
+    if (tid != 0) return;
+    TNode root{};
+    root.begin = 0; root.end = a.T; root.mid = 0; root.depth = 0; root.work = -1; root.cb_valid = 1;
+    for (int k = 0; k < 6; ++k) root.cb[k] = k < 3 ? kEncPosMax : kEncNegMax;
+    a.nodes[0] = root;
+    LevelCounters& l0 = a.counters[0];
+    l0.n_nodes = 1;
+    if (a.T <= (uint32_t)kTinyMax) l0.n_tiny = 1; else if (a.T <= (uint32_t)kSmallMax) l0.n_small = 1;
+    else if (a.T <= (uint32_t)kMediumMax) l0.n_medium = 1; else l0.n_big = 1;
+}
+
 __global__ __launch_bounds__(256) void k_check_verts(const float* verts3, uint64_t n3, LevelCounters* lc) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n3) return;
@@ -1042,8 +1063,11 @@ __global__ __launch_bounds__(256) void k_big_bin(const Params P, const BigWork* 
     }
 }
 
-__global__ __launch_bounds__(192) void k_big_eval(const Params P, BigWork* work, const int* gbins, LevelCounters* lc,
-                                                  uint32_t* median_list) {
+// The bins are left EMPTY for the next level: this workgroup clears the slot it has read and slot + gridDim.x (a level has
+// at most twice as many big nodes as the one above it, so slots [0, 2 nb) cover it; `slots_cap` bounds the array) -- the
+// k_big_bins_init launch per level is gone, only the first big level still needs it.
+__global__ __launch_bounds__(192) void k_big_eval(const Params P, BigWork* work, int* gbins, LevelCounters* lc,
+                                                  uint32_t* median_list, uint32_t slots_cap) {
     __shared__ BestRec s_best[3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t slot = blockIdx.x;
@@ -1065,7 +1089,16 @@ __global__ __launch_bounds__(192) void k_big_eval(const Params P, BigWork* work,
         for (int k = 0; k < 6; ++k) { br.lbox[k] = r.lbox[k]; br.rbox[k] = r.rbox[k]; }
     }
     if (lane == 0) s_best[wave] = br;
-    __syncthreads();
+    __syncthreads();                     // every wave has read its axis' bins
+    for (uint32_t which = 0; which < 2; ++which) {
+        const uint32_t sl = slot + which * gridDim.x;
+        if (sl >= slots_cap) break;
+        int* gb = gbins + (size_t)sl * 3 * 7 * kBinsN;
+        for (int i = tid; i < 3 * 7 * kBinsN; i += 192) {
+            const int k = (i / kBinsN) % 7;
+            gb[i] = k < 3 ? kEncPosMax : (k < 6 ? kEncNegMax : 0);
+        }
+    }
     if (tid != 0) return;
     double best_cost = 1.7976931348623157e308;
     int best_axis = -1;
@@ -1400,14 +1433,27 @@ __global__ __launch_bounds__(256) void k_write_nodes(const TNode* nodes, uint32_
 }
 
 // 48-byte triangle records in slot order, ids, labels (same expressions as bvh_build.cpp)
+struct QSummary { double isum; uint64_t icnt; uint32_t qfail, pad; };
 __global__ __launch_bounds__(256) void k_tri_records(const float* verts3, const uint32_t* tris3, const uint16_t* sem,
                                                      const uint16_t* ins, const uint32_t* final_id, uint32_t T,
                                                      float4* out_tris, uint32_t* slot_prim, uint32_t* slot_label,
-                                                     float* slot_box) {
+                                                     float* slot_box, const double* infl_part, const uint32_t* infl_cnt,
+                                                     uint32_t infl_n, const uint32_t* qfail, QSummary* summary) {
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s >= T + 3u) return;
     float4* o = out_tris + (size_t)s * 3;
-    if (s >= T) { o[0] = o[1] = o[2] = make_float4(0.f, 0.f, 0.f, 0.f); return; }     // padding records
+    if (s >= T) {                                     // padding records
+        o[0] = o[1] = o[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s == T + 2u) {
+            // the quantisation summary of k_write_nodes (the launch before this one), added up in block order as the host
+            // used to after three read-backs: one thread, one read-back
+            double isum = 0.0;
+            uint64_t icnt = 0;
+            for (uint32_t k = 0; k < infl_n; ++k) { isum += infl_part[k]; icnt += infl_cnt[k]; }
+            summary->isum = isum; summary->icnt = icnt; summary->qfail = qfail[0]; summary->pad = 0;
+        }
+        return;
+    }
     const uint32_t id = final_id[s];
     const float* v0 = verts3 + 3 * (size_t)tris3[3 * (size_t)id];
     const float* v1 = verts3 + 3 * (size_t)tris3[3 * (size_t)id + 1];
@@ -1486,10 +1532,10 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
         c.take<BigWork>(nbig_cap); c.take<uint32_t>(nbig_cap + 1); c.take<int>(nbig_cap * 3 * 7 * kBinsN);
         c.take<uint32_t>(nbig_cap);
         c.take<uint32_t>(list_cap / 256 + 2);
-        c.take<LevelCounters>(kMaxLevels + 1); c.take<int>(8);
+        c.take<LevelCounters>(kMaxLevels + 2);
         c.take<uint64_t>(T); c.take<uint64_t>(T); c.take<uint32_t>(T); c.take<uint32_t>(T); c.take<uint32_t>(T);
         c.take<double>((size_t)T / 256 + 2); c.take<uint32_t>((size_t)T / 256 + 2); c.take<uint32_t>(4);
-        c.take<SNode>(T); c.take<SubRoot>(list_cap); c.take<SubInfo>(list_cap); c.take<uint32_t>(list_cap); c.take<uint32_t>(8);
+        c.take<SNode>(T); c.take<SubRoot>(list_cap); c.take<SubInfo>(list_cap); c.take<uint32_t>(list_cap); c.take<uint32_t>(16);
         need = c.off;
     }
     if (arena->cap < need) {
@@ -1525,8 +1571,10 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     int* gbins = c.take<int>(nbig_cap * 3 * 7 * kBinsN);
     uint32_t* median_list = c.take<uint32_t>(nbig_cap);
     uint32_t* partial = c.take<uint32_t>(list_cap / 256 + 2);
-    LevelCounters* counters = c.take<LevelCounters>(kMaxLevels + 1);
-    int* bounds = c.take<int>(8);
+    // [0]: the scene bounds (8 ints), [1 ...]: the level counters -- bounds and level 0 come back in one copy
+    LevelCounters* counters = c.take<LevelCounters>(kMaxLevels + 2) + 1;
+    int* bounds = (int*)(counters - 1);
+    static_assert(sizeof(LevelCounters) >= 32, "the bounds share a LevelCounters slot");
     uint64_t* keys_in = c.take<uint64_t>(T);
     uint64_t* keys_out = c.take<uint64_t>(T);
     uint32_t* vals_in = c.take<uint32_t>(T);
@@ -1539,7 +1587,7 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     SubRoot* sub_roots = c.take<SubRoot>(list_cap);
     SubInfo* sub_info = c.take<SubInfo>(list_cap);
     uint32_t* sub_bases = c.take<uint32_t>(list_cap);
-    uint32_t* sub_count = c.take<uint32_t>(8);             // [0] roots so far; [4..7] SubTotals
+    uint32_t* sub_count = c.take<uint32_t>(16);            // [0] roots so far; [4..7] SubTotals; [8..13] QSummary
     {
         size_t tmp = 0;
         (void)rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)T, 0, 64, st);
@@ -1551,33 +1599,21 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     }
 
     // ---- level 0 ----
-    DB_HIP(hipMemsetAsync(counters, 0, sizeof(LevelCounters) * (kMaxLevels + 1), st));
-    DB_HIP(hipMemsetAsync(qfail, 0, 16, st));
-    DB_HIP(hipMemsetAsync(sub_count, 0, 32, st));
     {
-        TNode root{};
-        root.begin = 0; root.end = T; root.mid = 0; root.depth = 0; root.work = -1; root.cb_valid = 1;
-        for (int k = 0; k < 6; ++k) root.cb[k] = k < 3 ? kEncPosMax : kEncNegMax;
-        int b8[8] = {kEncPosMax, kEncPosMax, kEncPosMax, kEncNegMax, kEncNegMax, kEncNegMax, 0, 0};
-        uint32_t first = 0;
-        LevelCounters l0{};
-        l0.n_nodes = 1;
-        if (T <= (uint32_t)kTinyMax) l0.n_tiny = 1; else if (T <= (uint32_t)kSmallMax) l0.n_small = 1;
-        else if (T <= (uint32_t)kMediumMax) l0.n_medium = 1; else l0.n_big = 1;
-        DB_HIP(hipMemcpyAsync(nodes, &root, sizeof(root), hipMemcpyHostToDevice, st));
-        DB_HIP(hipMemcpyAsync(bounds, b8, sizeof(b8), hipMemcpyHostToDevice, st));
-        DB_HIP(hipMemcpyAsync(counters, &l0, sizeof(l0), hipMemcpyHostToDevice, st));
-        for (int k = 0; k < 4; ++k) DB_HIP(hipMemcpyAsync(lists[0][k], &first, 4, hipMemcpyHostToDevice, st));
-        DB_HIP(hipStreamSynchronize(st));      // the stack temporaries above must outlive their copies
+        SetupArgs sa{};
+        sa.nodes = nodes; sa.counters = counters; sa.bounds = bounds; sa.qfail = qfail; sa.sub_count = sub_count; sa.T = T;
+        for (int k = 0; k < 4; ++k) sa.list0[k] = lists[0][k];
+        hipLaunchKernelGGL(k_setup, dim3(1), dim3(256), 0, st, sa);
     }
     hipLaunchKernelGGL(k_check_verts, dim3((uint32_t)((3 * V + 255) / 256)), dim3(256), 0, st, d_verts, 3 * V, counters);
     hipLaunchKernelGGL(k_init_prims, dim3((T + 255) / 256), dim3(256), 0, st, d_verts, V, d_tris, T, bufA, nodes, bounds,
                        counters);
-    struct Landing { LevelCounters lc; int bounds[8]; uint32_t median[64]; };
+    struct Landing { LevelCounters b_lc[2]; LevelCounters lc; LevelCounters lc_pair[2]; int bounds[8]; uint32_t median[64]; };
     Landing* land = (Landing*)arena->pinned;
-    DB_HIP(hipMemcpyAsync(&land->lc, counters, sizeof(LevelCounters), hipMemcpyDeviceToHost, st));
-    DB_HIP(hipMemcpyAsync(land->bounds, bounds, 32, hipMemcpyDeviceToHost, st));
+    DB_HIP(hipMemcpyAsync(land->b_lc, counters - 1, 2 * sizeof(LevelCounters), hipMemcpyDeviceToHost, st));
     DB_HIP(hipStreamSynchronize(st));
+    std::memcpy(land->bounds, &land->b_lc[0], 32);
+    land->lc = land->b_lc[1];
     if (land->lc.error & 1u) { if (err) *err = "lrc_scene_create: triangle index out of range"; return LRC_ERR_INVALID_ARG; }
     if (land->lc.error & 2u) { if (err) *err = "lrc_scene_create: vertex coordinate is not finite or exceeds 1e6"; return LRC_ERR_INVALID_ARG; }
     auto host_dec = [](int i) { int u = i ^ ((i >> 31) & 0x7FFFFFFF); float f; std::memcpy(&f, &u, 4); return f; };
@@ -1600,6 +1636,7 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     uint64_t num_leaves = 0;
     uint32_t max_leaf_seen = 0;
     LevelCounters lc = land->lc;
+    bool bins_clean = false;
     while (lc.n_nodes > 0) {
         if (level + 1 >= (uint32_t)kMaxLevels || (uint64_t)base + lc.n_nodes > T) {
             if (err) *err = "device BVH build: level bookkeeping out of range";
@@ -1609,39 +1646,22 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
         uint32_t** L = lists[level & 1];
         uint32_t** Ln = lists[(level + 1) & 1];
         LevelCounters* cl = counters + level;
-        if (lc.n_big) {
-            const uint32_t nb = lc.n_big;
-            const uint32_t max_chunks = T / kChunk + nb + 1;
+        // ONE host synchronisation per level: the counters of this level (has the SAH failed on a big node?) and of the next
+        // come back together after the whole level has been enqueued.  A big node the SAH could not split (never on the
+        // meshes measured; `median_only` forces it) is ranked by a radix sort of its segment afterwards, and the level's
+        // emission -- which copied that node's children's bounds -- is done again.
+        const uint32_t nb = lc.n_big;
+        const uint32_t max_chunks = T / kChunk + nb + 1;
+        if (nb) {
             hipLaunchKernelGGL(k_big_prefix, dim3(1), dim3(1024), 0, st, nodes, L[2], nb, work, chunk_start);
-            const uint32_t total = nb * 3 * 7 * kBinsN;
-            hipLaunchKernelGGL(k_big_bins_init, dim3((total + 255) / 256), dim3(256), 0, st, gbins, total);
-            hipLaunchKernelGGL(k_big_bin, dim3(max_chunks), dim3(256), 0, st, P, work, chunk_start, nb, gbins);
-            hipLaunchKernelGGL(k_big_eval, dim3(nb), dim3(192), 0, st, P, work, gbins, cl, median_list);
-            hipLaunchKernelGGL(k_big_scatter, dim3(max_chunks), dim3(256), 0, st, P, work, chunk_start, nb);
-            // big nodes the SAH could not split: rank by (centroid, row) with a radix sort of the segment
-            DB_HIP(hipMemcpyAsync(&land->lc, cl, sizeof(LevelCounters), hipMemcpyDeviceToHost, st));
-            DB_HIP(hipStreamSynchronize(st));
-            uint32_t nmed = land->lc.n_median;
-            if (nmed) {
-                std::vector<uint32_t> slots(nmed);
-                std::vector<BigWork> hw(nb);
-                DB_HIP(hipMemcpy(slots.data(), median_list, nmed * 4, hipMemcpyDeviceToHost));
-                DB_HIP(hipMemcpy(hw.data(), work, nb * sizeof(BigWork), hipMemcpyDeviceToHost));
-                for (uint32_t q = 0; q < nmed; ++q) {
-                    const BigWork& w = hw[slots[q]];
-                    TNode hn;
-                    DB_HIP(hipMemcpy(&hn, nodes + w.g, sizeof(TNode), hipMemcpyDeviceToHost));
-                    const uint32_t n = hn.end - hn.begin;
-                    hipLaunchKernelGGL(k_median_keys, dim3((n + 255) / 256), dim3(256), 0, st, (const PrimRec*)cur, hn.begin,
-                                       n, w.axis, keys_in, vals_in);
-                    size_t tmp = arena->sort_cap;
-                    hipError_t se = rocprim::radix_sort_pairs(arena->sort_tmp, tmp, keys_in, keys_out, vals_in, vals_out,
-                                                              (size_t)n, 0, 64, st);
-                    DB_HIP(se);
-                    hipLaunchKernelGGL(k_median_gather, dim3((n + 255) / 256), dim3(256), 0, st, P, work + slots[q], n,
-                                       (const uint32_t*)vals_out);
-                }
+            if (!bins_clean) {
+                const uint32_t total = nb * 3 * 7 * kBinsN;
+                hipLaunchKernelGGL(k_big_bins_init, dim3((total + 255) / 256), dim3(256), 0, st, gbins, total);
             }
+            hipLaunchKernelGGL(k_big_bin, dim3(max_chunks), dim3(256), 0, st, P, work, chunk_start, nb, gbins);
+            hipLaunchKernelGGL(k_big_eval, dim3(nb), dim3(192), 0, st, P, work, gbins, cl, median_list, (uint32_t)nbig_cap);
+            hipLaunchKernelGGL(k_big_scatter, dim3(max_chunks), dim3(256), 0, st, P, work, chunk_start, nb);
+            bins_clean = true;           // slots [0, 2 nb) are empty again
         }
         if (lc.n_medium) hipLaunchKernelGGL(k_medium, dim3(lc.n_medium), dim3(256), 0, st, P, (const uint32_t*)L[1]);
         if (lc.n_small)
@@ -1652,12 +1672,45 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
         // Children of <= 64 primitives become subtree roots (k_subtree, one launch after the last level) once the numbers
         // handed out lie beyond the breadth-first head of the final layout, whose numbers must stay breadth-first.
         const int sub_mode = sub_enabled && (uint64_t)base + lc.n_nodes > (uint64_t)std::max(opt.bfs_nodes, 1) ? 1 : 0;
-        hipLaunchKernelGGL(k_emit_count, dim3(nblk), dim3(256), 0, st, (const TNode*)nodes, base, lc.n_nodes, max_leaf, partial);
-        hipLaunchKernelGGL(k_emit_write, dim3(nblk), dim3(256), 0, st, nodes, base, lc.n_nodes, base + lc.n_nodes, max_leaf,
-                           (const uint32_t*)partial, (const BigWork*)work, Ln[3], Ln[0], Ln[1], Ln[2], counters + level + 1,
-                           sub_mode, sub_roots, sub_count, (level + 1) & 1u);
-        DB_HIP(hipMemcpyAsync(&land->lc, counters + level + 1, sizeof(LevelCounters), hipMemcpyDeviceToHost, st));
+        auto emit = [&]() {
+            // a level of at most 256 nodes is one workgroup: nothing in front of it to count
+            if (nblk > 1)
+                hipLaunchKernelGGL(k_emit_count, dim3(nblk), dim3(256), 0, st, (const TNode*)nodes, base, lc.n_nodes, max_leaf, partial);
+            hipLaunchKernelGGL(k_emit_write, dim3(nblk), dim3(256), 0, st, nodes, base, lc.n_nodes, base + lc.n_nodes, max_leaf,
+                               (const uint32_t*)partial, (const BigWork*)work, Ln[3], Ln[0], Ln[1], Ln[2], counters + level + 1,
+                               sub_mode, sub_roots, sub_count, (level + 1) & 1u);
+        };
+        emit();
+        DB_HIP(hipMemcpyAsync(land->lc_pair, cl, 2 * sizeof(LevelCounters), hipMemcpyDeviceToHost, st));
         DB_HIP(hipStreamSynchronize(st));
+        if (nb && land->lc_pair[0].n_median) {
+            const uint32_t nmed = land->lc_pair[0].n_median;
+            std::vector<uint32_t> slots(nmed);
+            std::vector<BigWork> hw(nb);
+            DB_HIP(hipMemcpy(slots.data(), median_list, nmed * 4, hipMemcpyDeviceToHost));
+            DB_HIP(hipMemcpy(hw.data(), work, nb * sizeof(BigWork), hipMemcpyDeviceToHost));
+            for (uint32_t q = 0; q < nmed; ++q) {
+                const BigWork& w = hw[slots[q]];
+                TNode hn;
+                DB_HIP(hipMemcpy(&hn, nodes + w.g, sizeof(TNode), hipMemcpyDeviceToHost));
+                const uint32_t n = hn.end - hn.begin;
+                hipLaunchKernelGGL(k_median_keys, dim3((n + 255) / 256), dim3(256), 0, st, (const PrimRec*)cur, hn.begin,
+                                   n, w.axis, keys_in, vals_in);
+                size_t tmp = arena->sort_cap;
+                hipError_t se = rocprim::radix_sort_pairs(arena->sort_tmp, tmp, keys_in, keys_out, vals_in, vals_out,
+                                                          (size_t)n, 0, 64, st);
+                DB_HIP(se);
+                hipLaunchKernelGGL(k_median_gather, dim3((n + 255) / 256), dim3(256), 0, st, P, work + slots[q], n,
+                                   (const uint32_t*)vals_out);
+            }
+            // the emission again, from the state before it: the next level's counters and the running count of subtree roots
+            DB_HIP(hipMemsetAsync(counters + level + 1, 0, sizeof(LevelCounters), st));
+            DB_HIP(hipMemcpyAsync(sub_count, &n_sub_roots, 4, hipMemcpyHostToDevice, st));
+            emit();
+            DB_HIP(hipMemcpyAsync(land->lc_pair, cl, 2 * sizeof(LevelCounters), hipMemcpyDeviceToHost, st));
+            DB_HIP(hipStreamSynchronize(st));
+        }
+        land->lc = land->lc_pair[1];
         base += lc.n_nodes;
         lc = land->lc;
         num_leaves += lc.n_leaves;
@@ -1739,24 +1792,20 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     hipLaunchKernelGGL(k_write_nodes, dim3(nblk), dim3(256), 0, st, (const TNode*)nodes, nn, (const uint32_t*)new_of_old,
                        (float4*)out->nodes, (uint4*)out->nodes_q, (float4*)out->nodes_n, qg, infl_part, infl_cnt, qfail, final_id);
     hipLaunchKernelGGL(k_tri_records, dim3((T + 3 + 255) / 256), dim3(256), 0, st, d_verts, d_tris, d_sem, d_ins,
-                       (const uint32_t*)final_id, T, (float4*)out->tris, out->slot_prim, out->slot_label, out->slot_box);
+                       (const uint32_t*)final_id, T, (float4*)out->tris, out->slot_prim, out->slot_label, out->slot_box,
+                       (const double*)infl_part, (const uint32_t*)infl_cnt, nblk, (const uint32_t*)qfail, (QSummary*)(sub_count + 8));
+    const hipError_t e_copy = hipMemcpyAsync(land->median, sub_count + 8, sizeof(QSummary), hipMemcpyDeviceToHost, st);
+    const hipError_t e_sync = hipStreamSynchronize(st);
     {
         hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { if (err) *err = std::string("device BVH build: ") + hipGetErrorString(e); return bail(LRC_ERR_HIP); }
+        if (e == hipSuccess) e = e_copy != hipSuccess ? e_copy : e_sync;
+        if (e != hipSuccess) { (void)hipGetLastError(); if (err) *err = std::string("device BVH build: ") + hipGetErrorString(e); return bail(LRC_ERR_HIP); }
     }
-    std::vector<double> hp(nblk);
-    std::vector<uint32_t> hc(nblk);
-    uint32_t hq = 0;
-    if (hipMemcpy(hp.data(), infl_part, nblk * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(hc.data(), infl_cnt, nblk * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(&hq, qfail, 4, hipMemcpyDeviceToHost) != hipSuccess) {
-        (void)hipGetLastError();
-        if (err) *err = "device BVH build: reading the quantisation summary back failed";
-        return bail(LRC_ERR_HIP);
-    }
-    double isum = 0.0;
-    uint64_t icnt = 0;
-    for (uint32_t k = 0; k < nblk; ++k) { isum += hp[k]; icnt += hc[k]; }
+    QSummary qs;
+    std::memcpy(&qs, land->median, sizeof(qs));
+    const double isum = qs.isum;
+    const uint64_t icnt = qs.icnt;
+    const uint32_t hq = qs.qfail;
     out->leaf_inflation = icnt ? isum / (double)icnt : 1.0;
     if (qg.enabled && (hq != 0 || (qmode < 2 && out->leaf_inflation > kQnodeMaxInflation))) {
         out->nodes_q = nullptr; out->nodes_n = nullptr;      // the float32 nodes serve alone (the bytes stay in the slab)

@@ -39,3 +39,16 @@ w = flat_nodes * 45 + flat_tris * 40
 for K in (1, 2, 4, 8):
     for how, arr in (("next tiles of the scanline", w[:len(w) // (64 * K) * 64 * K].reshape(-1, K, 64).sum(1)),):
         print(f"K={K} rays per lane ({how}): work balance mean/max = {arr.mean() / arr.max(1).mean():.2f}")
+# Lever "waves with few live lanes switch to the four-wide image" (VERDICT r03 item 7a), the counter first: under lock step a
+# wave runs max-over-lanes node iterations and lane l is live in the first nodes_l of them, so the iterations run with at most N
+# live lanes number c(1) - c(N+1) (c = the wave's per-lane counts, descending).  Their share of ALL node iterations of all waves
+# bounds what any change confined to those iterations can save (a four-wide step there halves the iterations at about twice the
+# instructions per iteration: it saves latency, not issue).
+srt = -np.sort(-nodes, axis=1)
+total_iters = srt[:, 0].sum()
+for N in (1, 2, 4, 8, 16, 32):
+    few = (srt[:, 0] - srt[:, N]).sum()
+    print(f"node iterations run with <= {N:2d} live lanes: {few / total_iters:6.1%} of all wave iterations")
+longest = np.argsort(-srt[:, 0])[:max(1, len(srt) // 1000)]
+print(f"the longest 0.1 % of waves ({len(longest)}): {srt[longest, 0].mean():.0f} iterations, of which with <= 8 live lanes "
+      f"{(srt[longest, 0] - srt[longest, 8]).sum() / srt[longest, 0].sum():.1%}, <= 16: {(srt[longest, 0] - srt[longest, 16]).sum() / srt[longest, 0].sum():.1%}")

@@ -252,6 +252,16 @@ def caller_path(scene, sensor, poses, dirs, mesh, reps=7):
         out["run_simulation_rays_per_s"] = n / float(np.median(ts[2:]))
         out["run_simulation_ms"] = float(np.median(ts[2:])) * 1e3
         out["run_simulation_ms_min"] = float(np.min(ts[2:])) * 1e3
+        if os.environ.get("LRC_BENCH_PROFILE_RUNSIM") == "1":             # where the call's time goes (stderr)
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            for _ in range(10):
+                sc = sim.run_simulation(wps)
+                del sc
+            pr.disable()
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(14)
         sim.raycast_engine.clear_cache()
     except Exception as e:                                               # noqa: BLE001 - a diagnostic figure only
         out["run_simulation_error"] = repr(e)

@@ -1439,21 +1439,28 @@ __global__ __launch_bounds__(256) void k_tri_records(const float* verts3, const 
                                                      float4* out_tris, uint32_t* slot_prim, uint32_t* slot_label,
                                                      float* slot_box, const double* infl_part, const uint32_t* infl_cnt,
                                                      uint32_t infl_n, const uint32_t* qfail, QSummary* summary) {
+    if (blockIdx.x == gridDim.x - 1) {
+        // one workgroup more than the records need: the quantisation summary of k_write_nodes (the launch before this one),
+        // which the host used to add up after three read-backs.  Thread t adds the partials t, t + 256, ... in that order, a
+        // tree over the 256 sums follows: the same value on every run.
+        __shared__ double s_sum[256];
+        __shared__ unsigned long long s_cnt[256];
+        double isum = 0.0;
+        unsigned long long icnt = 0;
+        for (uint32_t k = threadIdx.x; k < infl_n; k += 256) { isum += infl_part[k]; icnt += infl_cnt[k]; }
+        s_sum[threadIdx.x] = isum; s_cnt[threadIdx.x] = icnt;
+        __syncthreads();
+        for (uint32_t off = 128; off >= 1; off >>= 1) {
+            if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { summary->isum = s_sum[0]; summary->icnt = s_cnt[0]; summary->qfail = qfail[0]; summary->pad = 0; }
+        return;
+    }
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s >= T + 3u) return;
     float4* o = out_tris + (size_t)s * 3;
-    if (s >= T) {                                     // padding records
-        o[0] = o[1] = o[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s == T + 2u) {
-            // the quantisation summary of k_write_nodes (the launch before this one), added up in block order as the host
-            // used to after three read-backs: one thread, one read-back
-            double isum = 0.0;
-            uint64_t icnt = 0;
-            for (uint32_t k = 0; k < infl_n; ++k) { isum += infl_part[k]; icnt += infl_cnt[k]; }
-            summary->isum = isum; summary->icnt = icnt; summary->qfail = qfail[0]; summary->pad = 0;
-        }
-        return;
-    }
+    if (s >= T) { o[0] = o[1] = o[2] = make_float4(0.f, 0.f, 0.f, 0.f); return; }     // padding records
     const uint32_t id = final_id[s];
     const float* v0 = verts3 + 3 * (size_t)tris3[3 * (size_t)id];
     const float* v1 = verts3 + 3 * (size_t)tris3[3 * (size_t)id + 1];
@@ -1791,7 +1798,7 @@ int build_bvh_device(DeviceArena* arena, const float* verts3, uint64_t V, const 
     hipLaunchKernelGGL(k_new_index, dim3(nblk), dim3(256), 0, st, head, nn, (const uint32_t*)vals_out, new_of_old);
     hipLaunchKernelGGL(k_write_nodes, dim3(nblk), dim3(256), 0, st, (const TNode*)nodes, nn, (const uint32_t*)new_of_old,
                        (float4*)out->nodes, (uint4*)out->nodes_q, (float4*)out->nodes_n, qg, infl_part, infl_cnt, qfail, final_id);
-    hipLaunchKernelGGL(k_tri_records, dim3((T + 3 + 255) / 256), dim3(256), 0, st, d_verts, d_tris, d_sem, d_ins,
+    hipLaunchKernelGGL(k_tri_records, dim3((T + 3 + 255) / 256 + 1), dim3(256), 0, st, d_verts, d_tris, d_sem, d_ins,
                        (const uint32_t*)final_id, T, (float4*)out->tris, out->slot_prim, out->slot_label, out->slot_box,
                        (const double*)infl_part, (const uint32_t*)infl_cnt, nblk, (const uint32_t*)qfail, (QSummary*)(sub_count + 8));
     const hipError_t e_copy = hipMemcpyAsync(land->median, sub_count + 8, sizeof(QSummary), hipMemcpyDeviceToHost, st);

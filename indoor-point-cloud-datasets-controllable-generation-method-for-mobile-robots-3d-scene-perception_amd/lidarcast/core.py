@@ -376,9 +376,14 @@ class Scene:
             f = np.zeros((0, 3), dtype=np.uint32)
         if f.ndim != 2 or f.shape[1] != 3:
             raise ValueError("triangles must be (T, 3)")
-        if f.size and (f.min() < 0):
-            raise ValueError("negative triangle index")
-        f = np.ascontiguousarray(f, dtype=np.uint32)
+        if f.dtype == np.int32 and f.flags.c_contiguous:
+            # no copy, no pass over the indices: a negative index reads as >= 2^31, which the build's own range check
+            # (index < V, on the device) rejects with the same ValueError
+            f = f.view(np.uint32)
+        else:
+            if f.size and f.dtype.kind != "u" and (f.min() < 0):
+                raise ValueError("negative triangle index")
+            f = np.ascontiguousarray(f, dtype=np.uint32)
         sem = None if tri_sem is None else np.ascontiguousarray(tri_sem, dtype=np.uint16)
         ins = None if tri_ins is None else np.ascontiguousarray(tri_ins, dtype=np.uint16)
         for lab in (sem, ins):

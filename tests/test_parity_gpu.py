@@ -136,6 +136,9 @@ def test_empty_and_tiny_inputs(ctx):
         scene.cast(np.zeros((4, 5), np.float32))
     with pytest.raises(ValueError):
         lidarcast.Scene(ctx, np.zeros((3, 3)), np.array([[0, 1, 3]]))        # index out of range
+    for dt in (np.int32, np.int64):                                          # a negative index: int32 goes in uncopied and is
+        with pytest.raises(ValueError):                                      # caught by the build's range check on the device
+            lidarcast.Scene(ctx, np.eye(3), np.array([[0, 1, -1]], dtype=dt))
     with pytest.raises(ValueError):
         lidarcast.Scene(ctx, np.full((3, 3), np.nan), np.array([[0, 1, 2]]))
 

@@ -591,7 +591,10 @@ def main():
             for pl in reversed(order):
                 dist_calibration[pl] = min(dist_calibration[pl], probe(pl))
             # "rows" leaves the close-up copy out, so it must win by more than that copy could cost to be chosen
+            # ... and another payload must beat the pipelined one by more than the probes' noise (3 %) to replace it
             dist_payload = min(("prim", "prim_pipe", "range"), key=lambda pl: dist_calibration[pl])
+            if dist_calibration[dist_payload] > 0.97 * dist_calibration["prim_pipe"]:
+                dist_payload = "prim_pipe"
         dist_step, dist_drain = make_dist(dist_payload)
 
     def step(timed):

@@ -2516,11 +2516,13 @@ int lrc_pipe_submit(lrc_pipe* pp, const double* d_poses16, uint64_t P, const dou
         // the scan pass over this scan's per-wave keep counts: 32-64 one-wave workgroups behind the trace; the rows follow
         // with this stream's next launch (or with lrc_pipe_wait)
         const uint64_t ntiles = P * (N / 64), nsuper = (ntiles + 1023) / 1024;
-        // FOUR waves: beside the other stream's running launch a kernel of this stream is handed a wave slot every few
-        // microseconds at best; 64 one-wave workgroups took 300 us to arrive (the next launch of this stream behind them), four
-        // are in within 20 us and done long before that launch has handed out its last workgroup
+        // One wave per super tile.  Beside the other stream's running launch a kernel of this stream is handed a wave slot
+        // every few microseconds at best, so in a long run four waves (in within 20 us, 80 us of work each) are 0.4 % ahead of
+        // 64 (arriving over 300 us: the next launch of this stream waits behind them) -- but a run ENDS with this pass alone on
+        // the GPU, where four waves take 80 us and 64 take 10: over blocks of 20 submits the wide pass is 2.4 % faster, over 300
+        // submits 0.4 % slower (profiles/r04_pipe_scan_width.txt).  Callers synchronise more often than every 300 batches.
 #ifndef LRC_PIPE_SCAN_WAVES
-#define LRC_PIPE_SCAN_WAVES 4
+#define LRC_PIPE_SCAN_WAVES 64
 #endif
         hipLaunchKernelGGL(compact_scan_kernel, dim3((uint32_t)(nsuper < LRC_PIPE_SCAN_WAVES ? nsuper : LRC_PIPE_SCAN_WAVES)), dim3(64), 0, T, (const uint32_t*)pp->rec[set].tile_count,
                            ntiles, (uint64_t)0, pp->scratch[lane].d_tile_off, ntiles, pp->scratch[lane].d_super_total);

@@ -7,6 +7,7 @@ raise -- the reference's caller catches engine construction errors itself
 """
 import ctypes as C
 import os
+import sys
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("LRC_LIB") or os.path.join(_PKG_ROOT, "liblidarcast.so")   # LRC_LIB: A/B builds
@@ -99,11 +100,36 @@ LRC_STATS_WORDS = 5
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  A PyTorch-ROCm wheel ships its own copy of libamdhip64.so and asks the loader for it under
+    that unversioned name, which never matches the SONAME (libamdhip64.so.7) of a copy that is already loaded; this library asks
+    for libamdhip64.so.7, which does match torch's copy.  So with torch imported first both share torch's runtime, and with this
+    library first the process ends up with two runtimes and torch finds no GPU ("No HIP GPUs are available").  When torch is
+    installed but not yet imported, load ITS runtime first (by path, without importing torch): the same arrangement either way.
+    LRC_SYSTEM_HIP_RUNTIME=1 keeps the system runtime (a process that will never import torch loses nothing either way)."""
+    if "torch" in sys.modules or os.environ.get("LRC_SYSTEM_HIP_RUNTIME") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    runtime = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(runtime):
+        try:
+            C.CDLL(runtime, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load liblidarcast.so once; raise RuntimeError when it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"liblidarcast.so not found at {LIB_PATH}: build it with "

@@ -91,3 +91,23 @@ def test_oracle_is_only_used_where_it_may_be():
         return found
     assert importers(os.path.join(REPO, "bench.py")) <= {"cpu_baseline"}
     assert importers(os.path.join(REPO, "__graft_entry__.py")) <= {"build", "smoke"}
+
+
+def test_one_hip_runtime_per_process_whichever_loads_first():
+    """A ROCm wheel of torch carries its own libamdhip64.so and asks the loader for it under that unversioned name; this
+    library asks for libamdhip64.so.7.  With this library loaded first (a single selected test does that) the process used to
+    end up with two HIP runtimes and torch with "No HIP GPUs are available".  lidarcast._capi.load() therefore loads torch's
+    copy first when torch is installed: in a fresh interpreter, in either order, exactly one runtime is mapped."""
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    pkg = os.path.dirname(__import__("lidarcast").LIB_PATH)
+    probe = ("import sys; sys.path.insert(0, %r)\n"
+             "%s\n"
+             "maps = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}\n"
+             "print(len(maps), sorted(maps))\n" % (pkg, "%s"))
+    for order in ("import lidarcast; lidarcast.load(); import torch", "import torch; import lidarcast; lidarcast.load()"):
+        r = subprocess.run([sys.executable, "-c", probe % order], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        n, paths = r.stdout.strip().split(" ", 1)
+        assert n == "1", f"{order}: HIP runtimes mapped: {paths}"

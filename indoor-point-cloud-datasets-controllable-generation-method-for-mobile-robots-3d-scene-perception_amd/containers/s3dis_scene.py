@@ -22,18 +22,25 @@ class RoomBounds:
         self.z_min, self.z_max = z_min, z_max
 
     # construction ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _column_bounds(v):
+        """``v.min(axis=0), v.max(axis=0)`` of a (V,3) array, column by column: the same values (a minimum is exact) as
+        numpy scalars of the same type, seven times faster -- numpy reduces an axis-0 minimum of a C-ordered (V,3) array three
+        elements at a time (8 ms for 300 k vertices: two thirds of a six-scene batch went there)."""
+        if v.ndim != 2 or v.shape[0] == 0:
+            return v.min(axis=0), v.max(axis=0)
+        return [v[:, k].min() for k in range(v.shape[1])], [v[:, k].max() for k in range(v.shape[1])]
+
     @classmethod
     def from_vertices(cls, vertices) -> "RoomBounds":
         """Bounds of a (V,3) array as Python floats -- what the simulator hands on (s3dis_simulator.py:93-101)."""
-        v = np.asarray(vertices)
-        lo, hi = v.min(axis=0), v.max(axis=0)
+        lo, hi = cls._column_bounds(np.asarray(vertices))
         return cls(float(lo[0]), float(hi[0]), float(lo[1]), float(hi[1]), float(lo[2]), float(hi[2]))
 
     @classmethod
     def from_mesh(cls, mesh) -> "RoomBounds":
         """Bounds of the mesh vertices, left as numpy scalars like the reference's."""
-        v = np.asarray(mesh.vertices)
-        lo, hi = v.min(axis=0), v.max(axis=0)
+        lo, hi = cls._column_bounds(np.asarray(mesh.vertices))
         return cls(x_min=lo[0], x_max=hi[0], y_min=lo[1], y_max=hi[1], z_min=lo[2], z_max=hi[2])
 
     @classmethod

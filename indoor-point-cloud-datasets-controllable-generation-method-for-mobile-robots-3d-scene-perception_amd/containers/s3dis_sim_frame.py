@@ -139,7 +139,7 @@ class S3DISSimFrame:
     def get_point_cloud_bounds(self) -> Dict[str, float]:
         if len(self.points) == 0:
             return {k: 0 for k in ("x_min", "x_max", "y_min", "y_max", "z_min", "z_max")}
-        lo, hi = self.points.min(axis=0), self.points.max(axis=0)
+        lo, hi = [self.points[:, k].min() for k in range(3)], [self.points[:, k].max() for k in range(3)]     # = min / max(axis=0)
         return {"x_min": float(lo[0]), "x_max": float(hi[0]), "y_min": float(lo[1]),
                 "y_max": float(hi[1]), "z_min": float(lo[2]), "z_max": float(hi[2])}
 

@@ -37,4 +37,4 @@ pr.enable()
 run_scene_batch([(n, meshes[n]) for n in names], traj, sensor=sensor, config={"raycast_engine": {"use_gpu": True}},
                 on_scene=lambda name, sc: seen.append(len(sc.frames)))
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+pstats.Stats(pr).strip_dirs().sort_stats("cumulative").print_stats(28)
